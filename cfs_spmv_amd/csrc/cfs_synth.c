@@ -1,0 +1,292 @@
+/*
+ * cfs_synth.c -- structure-faithful synthetic stand-ins for the SuiteSparse
+ * matrices BASELINE.json names (the real .mtx files are not available offline).
+ *
+ * Workload generation only: no SpMV arithmetic lives here.  Definitions follow
+ * symmetric, full nonzero diagonal, int32 indices,
+ * seed = FNV-1a(name), off-diagonal values U(-1,0), diag = 1 + sum |row|,
+ * x_i = 0.01 + 0.41 u_i with u from a 64-bit LCG seeded 42 (mirrors the
+ * U(0.01,0.42) of the reference driver, bench/bench_spmv_mmf.cpp:125).
+ *
+ * The generator emits the FULL (both triangles) CSR exactly as the reference's
+ * CSRMatrix holds it before tune() (rows ascending, columns ascending inside a
+ * row, 0-based; include/matrix/csr_matrix.tpp:74-107), because that is what
+ * the C ABI (include/cfs_hip.h) takes.
+ */
+#define _GNU_SOURCE
+#include <math.h>
+#include <omp.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline uint64_t splitmix64(uint64_t z) {
+  z += 0x9e3779b97f4a7c15ULL;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL;
+  return z ^ (z >> 31);
+}
+static inline double u01(uint64_t h) { /* (0,1] */
+  return ((double)(h >> 11) + 1.0) * (1.0 / 9007199254740992.0);
+}
+static uint64_t fnv1a(const char *s) {
+  uint64_t h = 0xcbf29ce484222325ULL;
+  for (; *s; s++) {
+    h ^= (unsigned char)*s;
+    h *= 0x100000001b3ULL;
+  }
+  return h;
+}
+/* symmetric off-diagonal value in [-1, 0): a function of the unordered pair */
+static inline double offdiag(uint64_t seed, int i, int j) {
+  uint64_t lo = (uint64_t)(i < j ? i : j), hi = (uint64_t)(i < j ? j : i);
+  return -u01(splitmix64(seed ^ (hi << 32 | lo)));
+}
+
+typedef struct {
+  int kind;           /* 0 = grid stencil, 1 = banded-random */
+  int n;              /* rows */
+  int nx, ny, nz, dof;/* grid */
+  int pts;            /* 27 or 7 */
+  int irregular;      /* ldoor-like: 2% fat rows, 5% thin rows */
+  int per_row, mean_off, cap_off; /* banded-random */
+  uint64_t seed;
+} spec_t;
+
+/* strictly-lower column list of row i (ascending, unique).  Returns count. */
+static int lower_cols(const spec_t *sp, int i, int *out, int cap) {
+  int cnt = 0;
+  if (sp->kind == 1) {
+    /* pdb1HYS-like: per_row draws at offsets 1 + floor(Exp(mean)) capped */
+    for (int k = 0; k < sp->per_row && cnt < cap; k++) {
+      uint64_t h = splitmix64(sp->seed ^ ((uint64_t)i * 1315423911ULL + (uint64_t)k));
+      double e = -log(u01(h)) * sp->mean_off;
+      int off = 1 + (int)e;
+      if (off > sp->cap_off) off = sp->cap_off;
+      int c = i - off;
+      if (c >= 0) out[cnt++] = c;
+    }
+  } else {
+    int dof = sp->dof, node = i / dof, d = i % dof;
+    int x = node % sp->nx, y = (node / sp->nx) % sp->ny, z = node / (sp->nx * sp->ny);
+    for (int dz = -1; dz <= 0; dz++)
+      for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+          if (sp->pts == 7 && (abs(dx) + abs(dy) + abs(dz)) > 1) continue;
+          int X = x + dx, Y = y + dy, Z = z + dz;
+          if (X < 0 || X >= sp->nx || Y < 0 || Y >= sp->ny || Z < 0) continue;
+          int nb = X + sp->nx * (Y + sp->ny * Z);
+          if (nb > node) continue;
+          for (int e = 0; e < dof; e++) {
+            int c = nb * dof + e;
+            if (c < i && cnt < cap) out[cnt++] = c;
+          }
+        }
+    (void)d;
+    if (sp->irregular) {
+      uint64_t h = splitmix64(sp->seed ^ (0xabcdef12345ULL + (uint64_t)i));
+      double u = u01(h);
+      if (u < 0.02) { /* fat row: ~3x extra lower entries in a local window */
+        int extra = 3 * cnt, win = 40000;
+        for (int k = 0; k < extra && cnt < cap; k++) {
+          uint64_t h2 = splitmix64(h + (uint64_t)k * 0x9e3779b97f4a7c15ULL);
+          int c = i - 1 - (int)(h2 % (uint64_t)win);
+          if (c >= 0) out[cnt++] = c;
+        }
+      } else if (u < 0.07) { /* thin row: keep only the 4 nearest */
+        /* applied after sort below */
+      }
+    }
+  }
+  /* sort + unique */
+  for (int a = 1; a < cnt; a++) {
+    int v = out[a], b = a - 1;
+    while (b >= 0 && out[b] > v) {
+      out[b + 1] = out[b];
+      b--;
+    }
+    out[b + 1] = v;
+  }
+  int u = 0;
+  for (int a = 0; a < cnt; a++)
+    if (a == 0 || out[a] != out[a - 1]) out[u++] = out[a];
+  cnt = u;
+  if (sp->kind == 0 && sp->irregular) {
+    uint64_t h = splitmix64(sp->seed ^ (0xabcdef12345ULL + (uint64_t)i));
+    double uu = u01(h);
+    if (uu >= 0.02 && uu < 0.07 && cnt > 4) {
+      memmove(out, out + (cnt - 4), 4 * sizeof(int));
+      cnt = 4;
+    }
+  }
+  return cnt;
+}
+
+static int make_spec(const char *name, double scale, spec_t *sp) {
+  memset(sp, 0, sizeof *sp);
+  sp->seed = fnv1a(name);
+  if (scale <= 0) scale = 1.0;
+  double s3 = cbrt(scale);
+  if (!strcmp(name, "pdb1HYS")) {
+    sp->kind = 1;
+    sp->n = (int)(36417 * scale);
+    sp->per_row = 62; /* ~59 unique lower nz/row after dedup */
+    sp->mean_off = 300;
+    sp->cap_off = 4000;
+  } else if (!strcmp(name, "pwtk")) {
+    sp->n = (int)(217918 * scale);
+    sp->dof = 2; sp->pts = 27;
+    sp->nx = (int)ceil(48 * s3); sp->ny = (int)ceil(48 * s3); sp->nz = (int)ceil(48 * s3);
+  } else if (!strcmp(name, "ldoor")) {
+    sp->n = (int)(952203 * scale);
+    sp->dof = 7; sp->pts = 7; sp->irregular = 1;
+    sp->nx = (int)ceil(52 * s3); sp->ny = (int)ceil(52 * s3); sp->nz = (int)ceil(51 * s3);
+  } else if (!strcmp(name, "Flan_1565")) {
+    sp->n = (int)(1564794 * scale);
+    sp->dof = 3; sp->pts = 27;
+    sp->nx = (int)ceil(81 * s3); sp->ny = (int)ceil(81 * s3); sp->nz = (int)ceil(80 * s3);
+  } else if (!strcmp(name, "Queen_4147")) {
+    sp->n = (int)(4147110 * scale);
+    sp->dof = 3; sp->pts = 27;
+    sp->nx = (int)ceil(112 * s3); sp->ny = (int)ceil(112 * s3); sp->nz = (int)ceil(111 * s3);
+  } else {
+    return -1;
+  }
+  if (sp->n < 1) sp->n = 1;
+  if (sp->kind == 0) {
+    /* the grid must hold ceil(n/dof) nodes; grow nz if rounding fell short */
+    long need = ((long)sp->n + sp->dof - 1) / sp->dof;
+    while ((long)sp->nx * sp->ny * sp->nz < need) sp->nz++;
+  }
+  return 0;
+}
+
+/* Generate matrix `name` ("pdb1HYS", "pwtk", "ldoor", "Flan_1565",
+ * "Queen_4147"), optionally scaled down (scale in (0,1]: n and the grid shrink
+ * together so the structure is preserved).  Output: full CSR, values as fp64
+ * (callers round to fp32 for the single-precision build).  Arrays are
+ * malloc'ed; free with cfs_synth_free.  Returns 0, or -1 for an unknown name. */
+int cfs_synth_generate(const char *name, double scale, int *n_out,
+                       long *nnz_full_out, long *nnz_low_out, int **rowptr_out,
+                       int **colind_out, double **values_out) {
+  spec_t sp;
+  if (make_spec(name, scale, &sp) != 0) return -1;
+  const int n = sp.n;
+  const int CAP = 2048;
+  /* pass 1: lower counts */
+  long *lptr = (long *)calloc((size_t)n + 1, sizeof(long));
+#pragma omp parallel
+  {
+    int *buf = (int *)malloc(sizeof(int) * CAP);
+#pragma omp for schedule(dynamic, 1024)
+    for (int i = 0; i < n; i++) lptr[i + 1] = lower_cols(&sp, i, buf, CAP);
+    free(buf);
+  }
+  for (int i = 0; i < n; i++) lptr[i + 1] += lptr[i];
+  long nnz_low = lptr[n];
+  int *lcol = (int *)malloc(sizeof(int) * (size_t)(nnz_low ? nnz_low : 1));
+#pragma omp parallel
+  {
+    int *buf = (int *)malloc(sizeof(int) * CAP);
+#pragma omp for schedule(dynamic, 1024)
+    for (int i = 0; i < n; i++) {
+      int c = lower_cols(&sp, i, buf, CAP);
+      memcpy(lcol + lptr[i], buf, sizeof(int) * (size_t)c);
+    }
+    free(buf);
+  }
+  /* full pattern: row i = lower(i) + diag + upper(i), upper(i) = rows r > i
+   * having i in lower(r): count by transposition                            */
+  long nnz_full = 2 * nnz_low + n;
+  if (nnz_full > 2147483647L) {
+    free(lptr);
+    free(lcol);
+    return -2; /* int32 nnz is API (src/csr.cpp:10-11) */
+  }
+  int *rowptr = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+  int *ucnt = (int *)calloc((size_t)n, sizeof(int));
+  for (long k = 0; k < nnz_low; k++) ucnt[lcol[k]]++;
+  rowptr[0] = 0;
+  for (int i = 0; i < n; i++)
+    rowptr[i + 1] = rowptr[i] + (int)(lptr[i + 1] - lptr[i]) + 1 + ucnt[i];
+  int *colind = (int *)malloc(sizeof(int) * (size_t)nnz_full);
+  double *values = (double *)malloc(sizeof(double) * (size_t)nnz_full);
+  int *upos = (int *)malloc(sizeof(int) * (size_t)n);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    int p = rowptr[i];
+    for (long k = lptr[i]; k < lptr[i + 1]; k++) {
+      colind[p] = lcol[k];
+      values[p] = offdiag(sp.seed, i, lcol[k]);
+      p++;
+    }
+    colind[p] = i; /* diagonal placeholder, value set below */
+    values[p] = 0.0;
+    upos[i] = p + 1;
+  }
+  /* upper entries: rows visited ascending => columns ascend inside each row */
+  for (int r = 0; r < n; r++)
+    for (long k = lptr[r]; k < lptr[r + 1]; k++) {
+      int i = lcol[k];
+      int p = upos[i]++;
+      colind[p] = r;
+      values[p] = offdiag(sp.seed, i, r);
+    }
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; i++) {
+    double s = 0.0;
+    int pd = -1;
+    for (int p = rowptr[i]; p < rowptr[i + 1]; p++) {
+      if (colind[p] == i) pd = p;
+      else s += fabs(values[p]);
+    }
+    values[pd] = 1.0 + s;
+  }
+  free(lptr);
+  free(lcol);
+  free(ucnt);
+  free(upos);
+  *n_out = n;
+  *nnz_full_out = nnz_full;
+  *nnz_low_out = nnz_low;
+  *rowptr_out = rowptr;
+  *colind_out = colind;
+  *values_out = values;
+  return 0;
+}
+
+void cfs_synth_free(void *p) { free(p); }
+
+/* x_i = 0.01 + 0.41 u_i, u from a 64-bit LCG (Knuth MMIX constants) seeded
+ * `seed` (42 for the benchmark vector).                                      */
+void cfs_synth_x(int n, uint64_t seed, double *x) {
+  uint64_t s = seed;
+  for (int i = 0; i < n; i++) {
+    s = s * 6364136223846793005ULL + 1442695040888963407ULL;
+    x[i] = 0.01 + 0.41 * ((double)(s >> 11) * (1.0 / 9007199254740992.0));
+  }
+}
+
+/* write a symmetric Matrix-Market file (lower triangle + diagonal, 1-based,
+ * single-space separated, trailing newline -- the dialect the reference reader
+ * accepts, src/mmf.cpp:26-44) from a full CSR.                               */
+int cfs_synth_write_mtx(const char *path, int n, const int *rowptr,
+                        const int *colind, const double *values, int general) {
+  FILE *f = fopen(path, "w");
+  if (!f) return -1;
+  long cnt = 0;
+  for (int i = 0; i < n; i++)
+    for (int p = rowptr[i]; p < rowptr[i + 1]; p++)
+      if (general || colind[p] <= i) cnt++;
+  fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n",
+          general ? "general" : "symmetric");
+  fprintf(f, "%% generated by cfs_synth.c\n");
+  fprintf(f, "%d %d %ld\n", n, n, cnt);
+  for (int i = 0; i < n; i++)
+    for (int p = rowptr[i]; p < rowptr[i + 1]; p++)
+      if (general || colind[p] <= i)
+        fprintf(f, "%d %d %.17g\n", i + 1, colind[p] + 1, values[p]);
+  fclose(f);
+  return 0;
+}

@@ -1,0 +1,206 @@
+/*
+ * cfs_hip.h -- C ABI of libcfs_hip.so: the MI355X (gfx950) symmetric-SpMV hot
+ * path of cfs-spmv behind plain pointers and sizes.
+ *
+ * This is the drop-in boundary.  The reference (athelaf/cfs-spmv) has no FFI of
+ * its own -- it is a C++ library whose hot path hides behind two seams:
+ *     tune()                   include/matrix/csr_matrix.tpp:230-310
+ *     dense_vector_multiply()  include/matrix/csr_matrix.hpp:67-70  (spmv_fn)
+ * and the allocation seam internal_alloc/internal_free
+ *     include/utils/allocator.hpp:11-12, src/allocator.cpp:8-43.
+ * Each entry point below names the reference interface it replaces.  The C++
+ * surface (include/cfs.hpp: SparseMatrix / CSRMatrix / SpDMV) and the Python
+ * mirror (cfs_spmv_amd/) are thin callers of this ABI; INTEGRATION.md shows
+ * the binding a maintainer of the reference would add.
+ *
+ * Conventions: every function returns 0 on success or a negative error code;
+ * cfs_hip_last_error() returns the message of the calling thread's last
+ * failure.  No C++ objects or exceptions cross this line.  Indices are int32
+ * (only <int,float> and <int,double> are instantiated in the reference:
+ * src/csr.cpp:10-11, src/cfs.cpp:11-21).
+ */
+#ifndef CFS_HIP_H
+#define CFS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFS_HIP_ABI_VERSION 1
+
+/* error codes */
+#define CFS_HIP_OK 0
+#define CFS_HIP_ERR_ARG (-1)      /* bad argument                            */
+#define CFS_HIP_ERR_DEVICE (-2)   /* HIP runtime failure (message has detail) */
+#define CFS_HIP_ERR_UNSUPPORTED (-3)
+#define CFS_HIP_ERR_NOMEM (-4)
+
+typedef struct cfs_hip_sym_s *cfs_hip_sym_t; /* symmetric (SSS) matrix handle */
+typedef struct cfs_hip_csr_s *cfs_hip_csr_t; /* general CSR matrix handle     */
+
+/* ---- runtime (replaces src/runtime.cpp:10-34: CFS_NUM_THREADS / affinity) -- */
+int cfs_hip_abi_version(void);
+const char *cfs_hip_last_error(void);
+int cfs_hip_device_count(int *count);
+/* Bind the calling process to `device` (one process per GPU).  Idempotent.   */
+int cfs_hip_init(int device);
+/* stream used internally by the synchronous (host-pointer capable) entry
+ * points; created by cfs_hip_init.  The *_async entry points take the caller's
+ * hipStream_t verbatim: NULL there means HIP's null stream (which is what
+ * torch.cuda.current_stream() is by default), never this one.               */
+int cfs_hip_default_stream(void **stream);
+int cfs_hip_synchronize(void *stream);
+
+/* ---- allocator (replaces internal_alloc / internal_free,
+ *      src/allocator.cpp:8-43; Platform::gpu memory)                      ---- */
+#define CFS_HIP_MEM_DEVICE 0 /* hipMalloc: HBM, the residency the timed loop needs */
+#define CFS_HIP_MEM_PINNED 1 /* hipHostMalloc: page-locked host staging buffer      */
+int cfs_hip_alloc(size_t bytes, int kind, void **out);
+int cfs_hip_free(void *p, int kind);
+#define CFS_HIP_H2D 0
+#define CFS_HIP_D2H 1
+#define CFS_HIP_D2D 2
+int cfs_hip_memcpy(void *dst, const void *src, size_t bytes, int dir);
+int cfs_hip_memset(void *dst, int value, size_t bytes);
+
+/* ---- tuning knobs of the tile schedule (all 0 = library default) ---------- */
+typedef struct {
+  int max_slots;     /* LDS slots (x and y windows) per tile               */
+  int max_tile_nnz;  /* cap on stored nonzeros per tile                    */
+  int block_threads; /* workgroup size of the tile kernel: 256, 512, 1024  */
+  int flags;         /* reserved                                            */
+} cfs_hip_options;
+
+/* ---- tune() for a symmetric matrix
+ *      (replaces CSRMatrix::tune -> compress_symmetry ->
+ *       conflict_free_aposteriori, csr_matrix.tpp:230-310, :1204-1639).
+ * Input is the FULL CSR exactly as CSRMatrix holds it before tune()
+ * (csr_matrix.tpp:74-107: 0-based, rows ascending, columns ascending), in host
+ * memory; the handle copies what it needs (the caller may free the arrays
+ * afterwards, as compress_symmetry does at :1700-1706).  Only entries with
+ * col <= row are read; a missing diagonal entry counts as 0.
+ *
+ * The *_shard_* forms build rank `rank`'s 1-D row block of a matrix sharded
+ * over `nranks` GPUs at row boundaries row_splits[0..nranks].    */
+int cfs_hip_sym_create_f64(int n, const int *rowptr, const int *colind,
+                           const double *values, const cfs_hip_options *opt,
+                           cfs_hip_sym_t *out);
+int cfs_hip_sym_create_f32(int n, const int *rowptr, const int *colind,
+                           const float *values, const cfs_hip_options *opt,
+                           cfs_hip_sym_t *out);
+int cfs_hip_sym_create_shard_f64(int n, const int *rowptr, const int *colind,
+                                 const double *values, int nranks, int rank,
+                                 const int *row_splits,
+                                 const cfs_hip_options *opt, cfs_hip_sym_t *out);
+int cfs_hip_sym_create_shard_f32(int n, const int *rowptr, const int *colind,
+                                 const float *values, int nranks, int rank,
+                                 const int *row_splits,
+                                 const cfs_hip_options *opt, cfs_hip_sym_t *out);
+/* nnz_low-balanced row boundaries (multiples of 16, csr_matrix.tpp:418) for
+ * sharding; row_splits has nranks+1 entries.                                 */
+int cfs_hip_sym_balanced_splits(int n, const int *rowptr, const int *colind,
+                                int nranks, int *row_splits);
+int cfs_hip_sym_destroy(cfs_hip_sym_t h);
+
+/* ---- dense_vector_multiply (replaces spmv_fn = cpu_mv_sym_conflict_free_v2,
+ *      csr_matrix.tpp:2965-3028).  y is fully overwritten (the reference test
+ *      never zeroes it: test/test_spmv_mmf.cpp:71,82-83); x and y must not
+ *      alias.  x has n entries, y has n entries (block rows for a shard).
+ *
+ * cfs_hip_sym_spmv      : x / y may be host or device pointers (detected);
+ *                         host pointers take the slow staged path; the call
+ *                         returns after the result is complete.
+ * cfs_hip_sym_spmv_async: device pointers only, enqueued on `stream`
+ *                         (a hipStream_t; NULL = HIP's null stream), returns
+ *                         immediately.                                       */
+int cfs_hip_sym_spmv(cfs_hip_sym_t h, void *y, const void *x);
+int cfs_hip_sym_spmv_async(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
+                           void *stream);
+
+/* ---- sharded operation: y_block = local rows; contributions to rows owned
+ *      by lower ranks are packed into send_buf (device), exchanged by the
+ *      caller (RCCL all-to-all / reduce-scatter), and folded in by
+ *      cfs_hip_sym_recv_fold.                                                */
+/* send_counts[r] = number of packed values destined to rank r (0 for r>=rank) */
+int cfs_hip_sym_shard_send_counts(cfs_hip_sym_t h, int *send_counts);
+/* global row index of every packed value, in send order (host array)        */
+int cfs_hip_sym_shard_send_rows(cfs_hip_sym_t h, int *rows);
+/* describe what this rank will receive: recv_rows are global row indices in
+ * receive-buffer order (concatenated by source rank), host array            */
+int cfs_hip_sym_shard_set_recv(cfs_hip_sym_t h, int nrecv, const int *recv_rows);
+int cfs_hip_sym_spmv_local_async(cfs_hip_sym_t h, void *y_block_dev,
+                                 const void *x_dev, void *send_buf_dev,
+                                 void *stream);
+int cfs_hip_sym_recv_fold_async(cfs_hip_sym_t h, void *y_block_dev,
+                                const void *recv_buf_dev, void *stream);
+
+/* ---- introspection (A->nnz(), A->size(), and what bench.py needs) --------- */
+typedef struct {
+  int n;               /* matrix order                                    */
+  int row_begin, row_end; /* rows owned by this handle                    */
+  int value_bytes;     /* 8 or 4                                          */
+  int64_t nnz_low;     /* stored strict-lower nonzeros of the owned rows  */
+  int64_t nnz_diag;    /* stored diagonal entries                         */
+  int64_t nnz_full;    /* expanded count = what A->nnz() reports          */
+  int ntiles, nslices, max_slots_used, block_threads;
+  int64_t halo_slots;  /* sum over tiles of halo (non-own) slots          */
+  int64_t fold_rows;   /* destination rows touched by the halo fold       */
+  int64_t remote_vals; /* packed values sent to lower ranks (shards)      */
+  int64_t lds_bytes;   /* dynamic LDS per workgroup                       */
+  /* algorithmic bytes of one SpMV over the owned rows, SURVEY.md 8(d):
+   * nnz_low*(4+s) + rows*(4+3s)                                          */
+  int64_t bytes_algorithmic;
+  /* bytes the device format actually streams per SpMV (values + 16-bit
+   * slots + per-row metadata + x/y + halo strips + fold index)           */
+  int64_t bytes_streamed;
+  int64_t device_bytes; /* device memory held by the handle               */
+} cfs_hip_sym_stats;
+int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out);
+
+/* ---- host-only self-check of the tile schedule (needs no GPU): builds the
+ *      schedule tune() would upload, decodes it back to (row, col, value)
+ *      triples and compares them with the strict lower triangle of the input;
+ *      also checks that the halo-fold index covers every strip entry once.
+ *      Structure only -- no SpMV arithmetic is performed on the host.      ---- */
+typedef struct {
+  int ntiles, ngroups, lds_slots;
+  int64_t nslices, halo_slots, stream_len, nnz_low, fold_rows, remote_vals;
+  int64_t decoded;    /* triples recovered from the device format           */
+  int64_t mismatches; /* 0 = the schedule encodes exactly the input         */
+} cfs_hip_plan_report;
+int cfs_hip_sym_plan_check_f64(int n, const int *rowptr, const int *colind,
+                               const double *values, int nranks, int rank,
+                               const int *row_splits, const cfs_hip_options *opt,
+                               cfs_hip_plan_report *report);
+int cfs_hip_sym_plan_check_f32(int n, const int *rowptr, const int *colind,
+                               const float *values, int nranks, int rank,
+                               const int *row_splits, const cfs_hip_options *opt,
+                               cfs_hip_plan_report *report);
+
+/* ---- general CSR (replaces cpu_mv / cpu_mv_serial, csr_matrix.tpp:2664-2704:
+ *      Format::csr and the silent fall-back for non-symmetric files,
+ *      csr_matrix.tpp:13-19)                                              ---- */
+int cfs_hip_csr_create_f64(int nrows, int ncols, const int *rowptr,
+                           const int *colind, const double *values,
+                           cfs_hip_csr_t *out);
+int cfs_hip_csr_create_f32(int nrows, int ncols, const int *rowptr,
+                           const int *colind, const float *values,
+                           cfs_hip_csr_t *out);
+int cfs_hip_csr_spmv(cfs_hip_csr_t h, void *y, const void *x);
+int cfs_hip_csr_spmv_async(cfs_hip_csr_t h, void *y_dev, const void *x_dev,
+                           void *stream);
+int cfs_hip_csr_destroy(cfs_hip_csr_t h);
+
+/* ---- HIP-event timing on the stream the kernels run on (bench.py) --------- */
+int cfs_hip_event_create(void **ev);
+int cfs_hip_event_record(void *ev, void *stream);
+int cfs_hip_event_elapsed_ms(void *start, void *stop, float *ms); /* syncs stop */
+int cfs_hip_event_destroy(void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFS_HIP_H */

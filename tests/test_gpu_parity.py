@@ -1,0 +1,148 @@
+"""GPU parity: the HIP tile kernel (through the C ABI) against the CPU oracle on
+the same seeded inputs.  Tolerances: fp64 1e-12, fp32 1e-5 relative to
+max(|y_ref|, sum_j |a_ij||x_j|); the reference's own
+criterion (rel. 1e-8 / 1e-4 element-wise, include/utils/platform.hpp:27-37) is
+asserted as well."""
+import numpy as np
+import pytest
+
+from conftest import scaled_err
+
+pytestmark = pytest.mark.gpu
+
+TOL = {np.float64: 1e-12, np.float32: 1e-5}
+REF_EPS = {np.float64: 1e-8, np.float32: 1e-4}
+
+
+def _torch():
+    import torch
+    assert torch.cuda.is_available(), "gpu test without a GPU"
+    return torch
+
+
+def _gpu_spmv(A, x, torch, garbage=777.0):
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    yd = torch.full((A.nrows(),), garbage, dtype=xd.dtype, device="cuda")
+    A.dense_vector_multiply(yd, xd)
+    torch.cuda.synchronize()
+    return yd.cpu().numpy()
+
+
+def _check(n, rp, ci, va, x, dtype, options=None, threads=(1, 4)):
+    import cfs_spmv_amd as cfs
+    from oracle import oracle
+    torch = _torch()
+    va = va.astype(dtype)
+    x = x.astype(dtype)
+    A = cfs.SymMatrix(n, rp, ci, va, options=options)
+    y = _gpu_spmv(A, x, torch)
+    y2 = _gpu_spmv(A, x, torch, garbage=-3.25)  # twice: y must be re-initialised
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    tol = TOL[dtype]
+    assert scaled_err(y, y_ld, absrow) <= tol
+    assert scaled_err(y2, y_ld, absrow) <= tol
+    for T in threads:
+        o = oracle.SymOracle(n, rp, ci, va, T)
+        y_ref = o.spmv(x)
+        assert scaled_err(y, y_ref.astype(np.float64), absrow) <= tol, f"T={T}"
+        o.close()
+    # the reference's own test: SSS result vs plain CSR result, element-wise
+    y_csr = oracle.csr_spmv(n, rp, ci, va, x)
+    well = absrow <= 1e3 * np.abs(y_csr)  # rows that do not cancel
+    assert np.all(np.abs(y[well] - y_csr[well]) <= REF_EPS[dtype] * np.abs(y[well]))
+    A.close()
+    return y
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name,scale", [("pdb1HYS", 0.25), ("pwtk", 0.05), ("ldoor", 0.02),
+                                        ("Flan_1565", 0.01)])
+def test_synth_parity(name, scale, dtype):
+    from cfs_spmv_amd import synth
+    n, rp, ci, va, _ = synth.generate(name, scale)
+    x = synth.make_x(n)
+    _check(n, rp, ci, va, x, dtype)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("n,avg,band,slots,block", [
+    (1, 0, None, 0, 0), (2, 1, None, 0, 0), (63, 3, None, 64, 256), (64, 3, None, 0, 256),
+    (65, 3, None, 0, 512), (300, 5, None, 64, 256), (1000, 20, 50, 128, 1024),
+    (5000, 8, None, 0, 0), (4097, 40, 300, 512, 512), (20000, 3, 2000, 2560, 256)])
+def test_random_parity(n, avg, band, slots, block, dtype):
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    n, rp, ci, va = synth.random_symmetric(n, avg, seed=n * 7 + avg, band=band)
+    rng = np.random.default_rng(n)
+    x = rng.uniform(-1.0, 1.0, size=n)  # mixed signs: cancelling rows
+    opt = cfs.make_options(max_slots=slots, block_threads=block)
+    _check(n, rp, ci, va, x, dtype, options=opt, threads=(1, 2) if n >= 64 else (1,))
+
+
+def test_ragged_and_empty_rows():
+    """rows with no lower entries, a missing diagonal, duplicates-free arrow"""
+    import scipy.sparse as sp
+    n = 700
+    rng = np.random.default_rng(3)
+    L = sp.lil_matrix((n, n))
+    for i in range(1, n):
+        if i % 3 == 0:
+            continue  # empty lower rows
+        k = int(rng.integers(1, 90)) if i % 50 else min(i, 400)
+        cols = np.unique(rng.integers(0, i, size=k))
+        L[i, cols] = rng.uniform(-2, 2, size=cols.size)
+    d = rng.uniform(1, 2, size=n)
+    d[10] = 0.0
+    A = (L + L.T + sp.diags(d)).tocsr()
+    A.eliminate_zeros()  # row 10 has no stored diagonal now
+    A.sort_indices()
+    x = rng.uniform(-1, 1, size=n)
+    _check(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, x, np.float64,
+           threads=(1,))
+
+
+def test_host_pointer_path_and_determinism():
+    """cfs_hip_sym_spmv with host pointers (the unmodified-caller path of
+    test/test_spmv_mmf.cpp) and run-to-run agreement"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from oracle import oracle
+    _torch()
+    n, rp, ci, va, _ = synth.generate("pwtk", 0.05)
+    x = synth.make_x(n)
+    A = cfs.SymMatrix(n, rp, ci, va)
+    f = cfs.SpDMV(A, cfs.Tuning.Aggressive)
+    y = np.full(n, 9.0)
+    f(y, n, x, n)
+    f(y, n, x, n)
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(y, y_ld, absrow) <= 1e-12
+    y3 = np.empty(n)
+    f(y3, n, x, n)
+    # LDS float atomics: the order of the transposed updates may vary run to run
+    assert scaled_err(y3, y, absrow) <= 1e-13
+    with pytest.raises(AssertionError):
+        f(y, n + 1, x, n)
+
+
+def test_csr_general_parity():
+    """Format::csr on the GPU against cpu_mv_serial (csr_matrix.tpp:2664-2681)"""
+    import scipy.sparse as sp
+    import cfs_spmv_amd as cfs
+    from oracle import oracle
+    torch = _torch()
+    for dtype in (np.float64, np.float32):
+        for (m, k, dens) in [(1000, 1000, 0.01), (513, 700, 0.05), (4000, 4000, 0.002)]:
+            A = sp.random(m, k, density=dens, random_state=5, format="csr", dtype=np.float64)
+            A.sort_indices()
+            rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(dtype)
+            x = np.random.default_rng(1).uniform(-1, 1, size=k).astype(dtype)
+            G = cfs.CsrMatrix(m, k, rp, ci, va)
+            xd = torch.from_numpy(x).cuda()
+            yd = torch.full((m,), 5.0, dtype=xd.dtype, device="cuda")
+            G.dense_vector_multiply(yd, xd)
+            torch.cuda.synchronize()
+            y = yd.cpu().numpy()
+            y_ld, absrow = oracle.csr_spmv_ld(m, rp, ci, va, np.resize(x, k))
+            assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
+            G.close()
