@@ -1,0 +1,261 @@
+#!/usr/bin/env python3
+"""bench.py -- the contract benchmark of the symmetric-SpMV hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one SpMV y <- A x of the hot path (tile kernel + halo fold, plus the
+exchange of off-block contributions when N > 1) on the Flan_1565 stand-in
+(BASELINE.json's headline config; the real .mtx is not available offline, the
+generator is SURVEY.md section 8d's), fp64, x and y resident in HBM.  The matrix
+is FIXED and sharded by 1-D row blocks, so scaling is "strong".
+
+Metric (BASELINE.json): GFLOP/s = 2*nnz_full / t, the reference driver's own
+formula (bench/bench_spmv_mmf.cpp:168), with the achieved algorithmic GB/s of
+the dominant kernel against the 8 TB/s HBM3E peak in "roofline", and the CPU
+oracle (the reference's OpenMP conflict-free path, restated) timed on this
+box's host cores in "cpu_baseline" (rank 0, N = 1 only).
+
+Only the cpu_baseline leg imports oracle/ -- as the reported baseline, never as
+the thing measured.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--matrix", default="Flan_1565")
+    ap.add_argument("--scale", type=float, default=1.0)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--max-slots", type=int, default=0)
+    ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-loops", type=int, default=32)
+    return ap.parse_args()
+
+
+def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
+    """the oracle's restatement of cpu_mv_sym_conflict_free_v2 on the host cores,
+    same matrix, same x, reference protocol (loops/2 warm-up, loops timed)"""
+    from oracle import oracle
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    T = max(1, min(cores, 96))  # MaxThreads = 96, include/utils/runtime.hpp:15
+    os.environ.setdefault("OMP_PROC_BIND", "close")
+    os.environ.setdefault("OMP_PLACES", "cores")
+    t0 = time.time()
+    o = oracle.SymOracle(n, rp, ci, va, T)
+    preproc = time.time() - t0
+    y = o.spmv(x_host)
+    for _ in range(loops // 2):
+        o.spmv(x_host, y)
+    t0 = time.time()
+    for _ in range(loops):
+        o.spmv(x_host, y)
+    dt = (time.time() - t0) / loops
+    info = o.info()
+    o.close()
+    return {
+        "value": round(2.0 * nnz_full / dt / 1e9, 2), "unit": "GFLOP/s", "cores": T,
+        "kind": "port",
+        "sample": f"whole workload: {loops // 2} warm-up + {loops} timed SpMVs of the "
+                  f"oracle's conflict-free v2 path ({info['ncolors']} colours), "
+                  f"preproc {preproc:.1f}s, {dt * 1e3:.2f} ms/SpMV",
+        "ms_per_step": round(dt * 1e3, 3),
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import _lib, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    N = args.gpus
+    if world != N and not (N == 1 and world == 1):
+        raise SystemExit(f"--gpus {N} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    lib = _lib.load()
+    _lib.check(lib.cfs_hip_init(local_rank))
+    dist = None
+    if N > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    np_dt = np.float64 if args.dtype == "f64" else np.float32
+    t_dt = torch.float64 if args.dtype == "f64" else torch.float32
+    n, rp, ci, va, nnz_low = synth.generate(args.matrix, args.scale)
+    va = va.astype(np_dt, copy=False)
+    nnz_full = int(rp[-1])
+    x_host = synth.make_x(n, 42, np_dt)
+    opt = cfs.make_options(max_slots=args.max_slots, block_threads=args.block)
+
+    t0 = time.time()
+    if N == 1:
+        A = cfs.SymMatrix(n, rp, ci, va, options=opt)
+        sh = None
+    else:
+        from cfs_spmv_amd.dist import ShardedSym
+        rs = cfs.balanced_splits(n, rp, ci, N)
+        A = cfs.SymMatrix(n, rp, ci, va, options=opt, row_splits=rs, rank=rank)
+        sh = ShardedSym(A, N, rank, np_dt, dev)
+    preproc = time.time() - t0
+    st = A.stats()
+    rows = st["row_end"] - st["row_begin"]
+    x = torch.from_numpy(x_host).to(dev)
+    y = torch.full((rows,), float("nan"), dtype=t_dt, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    send = sh.send_buf if sh is not None else None
+
+    import ctypes as C
+
+    def new_event():
+        e = C.c_void_p()
+        _lib.check(lib.cfs_hip_event_create(C.byref(e)))
+        return e
+
+    K = args.steps
+    ev0 = [new_event() for _ in range(K)]
+    ev1 = [new_event() for _ in range(K)]
+
+    def step(i=None):
+        # one SpMV = tile kernel (the roofline kernel) + halo fold (+ exchange).
+        # In the timed region the tile kernel is bracketed by HIP events recorded
+        # on the stream it is launched on.
+        if i is not None:
+            _lib.check(lib.cfs_hip_event_record(ev0[i], stream))
+        A.spmv_phases(y, x, send, 1)
+        if i is not None:
+            _lib.check(lib.cfs_hip_event_record(ev1[i], stream))
+        A.spmv_phases(y, x, send, 2)
+        if sh is not None:
+            sh.exchange_and_fold(y)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps between barrier+synchronize pairs --------
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    ms_per_step = elapsed / K * 1e3
+
+    # ---- roofline: average duration of the tile kernel over the timed region ----
+    tile_total = 0.0
+    ms = C.c_float()
+    for i in range(K):
+        _lib.check(lib.cfs_hip_event_elapsed_ms(ev0[i], ev1[i], C.byref(ms)))
+        tile_total += ms.value
+    tile_ms = tile_total / K
+    for e in ev0 + ev1:
+        lib.cfs_hip_event_destroy(e)
+
+    alg_bytes = st["bytes_algorithmic"]  # this rank's rows: nnz_low*(4+s) + rows*(4+3s)
+    achieved = alg_bytes / (tile_ms * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            with open(tpath) as f:
+                tj = json.load(f)
+            key = f"{args.matrix}:{args.scale}:{args.dtype}:{N}"
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    # quick self-check of the timed result against the plain-CSR row sums (GPU CSR
+    # kernel, not the oracle): guards against timing a broken kernel
+    ok = True
+    if N == 1:
+        G = cfs.CsrMatrix(n, n, rp, ci, va)
+        y2 = torch.empty_like(y)
+        G.dense_vector_multiply(y2, x)
+        torch.cuda.synchronize()
+        scale = torch.maximum(y2.abs(), torch.tensor(1.0, dtype=t_dt, device=dev))
+        err = float(((y - y2).abs() / scale).max().item())
+        ok = err < (1e-9 if args.dtype == "f64" else 1e-3)
+        G.close()
+        if not ok:
+            raise SystemExit(f"self-check failed: max scaled |y - y_csr| = {err}")
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "fp64 symmetric SpMV GFLOP/s" if args.dtype == "f64"
+                      else "fp32 symmetric SpMV GFLOP/s",
+            "value": round(2.0 * nnz_full / (ms_per_step * 1e-3) / 1e9, 2),
+            "unit": "GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {
+                "workload": f"{args.matrix}-like synthetic (SURVEY 8d generator), "
+                            f"scale {args.scale}: n={n}, nnz_full={nnz_full}, "
+                            f"nnz_low={nnz_low}, symmetric SSS SpMV y=Ax",
+                "format": "sss", "sharding": f"1d-row-blocks x{N}",
+                "algorithmic_bytes_per_spmv": int(nnz_low * (4 + va.itemsize)
+                                                  + n * (4 + 3 * va.itemsize)),
+                "effective_GBps_whole_step": round(
+                    (nnz_low * (4 + va.itemsize) + n * (4 + 3 * va.itemsize))
+                    / (ms_per_step * 1e-3) / 1e9, 1),
+                "tiles": st["ntiles"], "lds_bytes": st["lds_bytes"],
+                "block_threads": st["block_threads"], "preproc_s": round(preproc, 2),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "cfs_sym_tile_kernel",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel_ms": round(tile_ms, 5),
+                "algorithmic_bytes_per_launch": int(alg_bytes),
+            },
+        }
+    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+        try:
+            out["cpu_baseline"] = cpu_baseline(n, rp, ci, va, x_host, nnz_full, args.cpu_loops)
+        except Exception as e:  # the baseline is reported, never required
+            out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0,
+                                   "kind": "port", "sample": f"failed: {e}"}
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -11,4 +11,4 @@ directory is `cfs_spmv_amd`.)
 """
 from ._lib import CfsHipError, load, lib_path  # noqa: F401
 from .matrix import (CsrMatrix, Format, Kernel, SpDMV, SymMatrix, Tuning,  # noqa: F401
-                     balanced_splits, make_options, plan_check)
+                     balanced_splits, make_options, plan_check, plan_send_info)

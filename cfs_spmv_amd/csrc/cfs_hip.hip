@@ -54,47 +54,127 @@ template <typename V> struct SymDev {
   const int32_t *halo_col;
   const uint32_t *rowinfo;
   const V *diag;
-  const uint32_t *slice_off;
+  const uint2 *slice_meta; // {entry offset inside the tile, lanes of packet 0}
   const V *vals;
   const uint16_t *slots;
+  const V *cvals; // COO leftovers (len % 4 per row): value, row slot, column slot
+  const uint16_t *crows;
+  const uint16_t *ccols;
   V *strip;
   int row_begin;
   int lds_slots;
 };
 
-template <typename V> struct Vec4;
-template <> struct Vec4<double> { double2 a, b; };
-template <> struct Vec4<float> { float4 a; };
+// one packet = 4 consecutive entries of the rows held by lanes [0, cnt): values
+// for lane l, entry j at cfs_plan::packet_val_pos<V>(l, j, cnt), slots at l*4+j.
+// Every lane issues the loads (lanes >= cnt re-read lane cnt-1's bytes: same
+// cache lines, no extra DRAM traffic) so that the loads are unconditional
+// instructions and the compiler's vmcnt bookkeeping stays exact.
+template <typename V> struct Pkt {
+  V v[4];
+  ushort4 c;
+};
 
-// one packet = 4 jagged diagonals x 64 lanes; values for lane l, diagonal j at
-// cfs_plan::packet_val_pos<V>(l, j), slots at l*4+j
-__device__ __forceinline__ void load_packet(const double *tv, uint32_t off, int lane,
-                                            double (&v)[4]) {
-  const double2 lo = *reinterpret_cast<const double2 *>(tv + off + lane * 2);
-  const double2 hi = *reinterpret_cast<const double2 *>(tv + off + 128 + lane * 2);
-  v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+__device__ __forceinline__ void fetch_packet(Pkt<double> &p, const double *tv,
+                                             const uint16_t *ts, uint32_t off, int cnt,
+                                             int lane) {
+  const int ll = min(lane, max(cnt, 1) - 1);
+  const double2 lo = *reinterpret_cast<const double2 *>(tv + off + ll * 2);
+  const double2 hi = *reinterpret_cast<const double2 *>(tv + off + 2 * cnt + ll * 2);
+  p.c = *reinterpret_cast<const ushort4 *>(ts + off + ll * 4);
+  p.v[0] = lo.x; p.v[1] = lo.y; p.v[2] = hi.x; p.v[3] = hi.y;
 }
-__device__ __forceinline__ void load_packet(const float *tv, uint32_t off, int lane,
-                                            float (&v)[4]) {
-  const float4 q = *reinterpret_cast<const float4 *>(tv + off + lane * 4);
-  v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+__device__ __forceinline__ void fetch_packet(Pkt<float> &p, const float *tv,
+                                             const uint16_t *ts, uint32_t off, int cnt,
+                                             int lane) {
+  const int ll = min(lane, max(cnt, 1) - 1);
+  const float4 q = *reinterpret_cast<const float4 *>(tv + off + ll * 4);
+  p.c = *reinterpret_cast<const ushort4 *>(ts + off + ll * 4);
+  p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
+}
+
+// one stored nonzero a = A[row][col(c)]: row side into the register
+// accumulator, transposed side into the LDS y window (ds_add_f64 / ds_add_f32)
+template <typename V, int MODE>
+__device__ __forceinline__ void lds_update(const V *xl, V *yl, V a, unsigned c, V xi, V &acc) {
+  if (MODE == 2) {
+    acc = fma(a, xi + V(c), acc);
+  } else {
+    acc = fma(a, xl[c], acc);
+    if (MODE == 0) atomicAdd(&yl[c], a * xi);
+  }
+}
+template <typename V, int MODE>
+__device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, V *yl, V xi, V &acc) {
+  lds_update<V, MODE>(xl, yl, p.v[0], p.c.x, xi, acc);
+  lds_update<V, MODE>(xl, yl, p.v[1], p.c.y, xi, acc);
+  lds_update<V, MODE>(xl, yl, p.v[2], p.c.z, xi, acc);
+  lds_update<V, MODE>(xl, yl, p.v[3], p.c.w, xi, acc);
+}
+// one COO leftover a = A[row(r)][col(c)]: both sides through LDS atomics
+template <typename V, int MODE>
+__device__ __forceinline__ void coo_update(const V *xl, V *yl, V a, unsigned r, unsigned c) {
+  if (MODE == 0 || MODE == 1) {
+    atomicAdd(&yl[r], a * xl[c]);
+    if (MODE == 0) atomicAdd(&yl[c], a * xl[r]);
+  }
 }
 
 // ---------------------------------------------------------------------------
 // tile kernel: persistent workgroups, each walks its group of tiles.
 //   prologue: x window -> LDS (own rows coalesced, halo gathered), y window = 0
 //   slices  : one lane = one row; row-side sum in a register, transposed
-//             updates into the LDS y window with ds_add_f64 / ds_add_f32
+//             updates into the LDS y window with ds_add_f64 / ds_add_f32.
+//             The matrix stream is software-pipelined per wave: the head
+//             packet of the NEXT slice is requested a whole slice ahead and
+//             packets ping-pong between two register sets, so a wave always
+//             has loads in flight, also across slice boundaries.  The len%4
+//             leftovers of the tile's rows are a flat COO section.
 //   epilogue: own rows -> y (plain coalesced stores, fully overwrites y),
 //             halo sums -> this tile's private strip (plain coalesced stores)
+// MODE 0 is the product kernel.  MODE 1/2 are timing-only ablations selected by
+// cfs_hip_options.flags (results are WRONG by construction; they exist to price
+// the LDS atomics / LDS gathers against the pure matrix stream, never shipped
+// as a result path): 1 = no transposed LDS atomics, 2 = no LDS traffic at all,
+// 3 = windows only (no matrix stream), 4 = matrix stream only (no windows).
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK>
+template <typename V, int BLOCK, int MODE>
 __global__ void __launch_bounds__(BLOCK)
-    cfs_sym_tile_kernel(const SymDev<V> d, const V *__restrict__ x, V *__restrict__ y) {
+    cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const int32_t *__restrict__ a_group_ptr,
+                        const int32_t *__restrict__ a_halo_col,
+                        const uint32_t *__restrict__ a_rowinfo, const V *__restrict__ a_diag,
+                        const uint2 *__restrict__ a_slice_meta, const V *__restrict__ a_vals,
+                        const uint16_t *__restrict__ a_slots, const V *__restrict__ a_cvals,
+                        const uint16_t *__restrict__ a_crows,
+                        const uint16_t *__restrict__ a_ccols, V *__restrict__ a_strip,
+                        const int a_row_begin, const int a_lds_slots,
+                        const V *__restrict__ x, V *__restrict__ y) {
+  // every array is a separate __restrict__ argument: read-only metadata at
+  // wave-uniform addresses then becomes scalar loads (s_load), off the vector
+  // memory counter the matrix stream is pipelined on
+  struct {
+    const Tile *__restrict__ tiles;
+    const int32_t *__restrict__ group_ptr;
+    const int32_t *__restrict__ halo_col;
+    const uint32_t *__restrict__ rowinfo;
+    const V *__restrict__ diag;
+    const uint2 *__restrict__ slice_meta;
+    const V *__restrict__ vals;
+    const uint16_t *__restrict__ slots;
+    const V *__restrict__ cvals;
+    const uint16_t *__restrict__ crows;
+    const uint16_t *__restrict__ ccols;
+    V *__restrict__ strip;
+    int row_begin, lds_slots;
+  } d = {a_tiles, a_group_ptr, a_halo_col, a_rowinfo, a_diag, a_slice_meta, a_vals,
+         a_slots, a_cvals, a_crows, a_ccols, a_strip, a_row_begin, a_lds_slots};
   extern __shared__ __align__(16) unsigned char cfs_smem[];
   V *xl = reinterpret_cast<V *>(cfs_smem);
   V *yl = xl + d.lds_slots;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // wave-uniform by construction: keep it in an SGPR so that slice bookkeeping is
+  // scalar (s_load / s_cbranch) and never waits on the vector-memory counter
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int NW = BLOCK / 64;
   // blocks b and b+8 share an XCD (round-robin dispatch): give every XCD a
   // contiguous run of groups so neighbouring tiles share halo lines in one L2.
@@ -103,68 +183,173 @@ __global__ void __launch_bounds__(BLOCK)
   const int g = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
   const int t0 = d.group_ptr[g], t1 = d.group_ptr[g + 1];
 
+  // x window of a tile, gathered into registers with every load in flight at
+  // once (two round trips: halo columns, then x).  Under a saturated memory
+  // system a round trip costs microseconds, so the window of the NEXT tile is
+  // requested before the barrier that ends the current tile's slices and lands
+  // while the y window is flushed.
+  constexpr int U = cfs_plan::kSlotsPerThread;
+  V xr[U];
+  auto gather_x = [&](const Tile &tn) {
+    // every load is unconditional (clamped index, select afterwards): a load
+    // under a divergent branch would make the compiler drain vmcnt before the
+    // other side of the branch may write the same register
+    int idx[U];
+    const int nh = tn.nslots - tn.nown;
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int i = tid + k * BLOCK;
+      const int hi = min(max(i - tn.nown, 0), max(nh - 1, 0));
+      idx[k] = d.halo_col[tn.halo_off + hi]; // halo_col is padded by one entry
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int i = tid + k * BLOCK;
+      idx[k] = i < tn.nown ? tn.row0 + i : (i < tn.nslots ? idx[k] : tn.row0);
+    }
+    if (MODE != 4) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) xr[k] = x[idx[k]];
+    } else {
+#pragma unroll
+      for (int k = 0; k < U; ++k) xr[k] = V(idx[k]);
+    }
+  };
+  if (t0 < t1) gather_x(d.tiles[t0]);
+  int prev_nown = 0, prev_nslots = 0, prev_lrow0 = 0, prev_halo_off = 0;
+
   for (int ti = t0; ti < t1; ++ti) {
     const Tile t = d.tiles[ti];
     const int nown = t.nown, nslots = t.nslots;
     const int lrow0 = t.row0 - d.row_begin;
-
-    for (int s = tid; s < nown; s += BLOCK) {
-      xl[s] = x[t.row0 + s];
-      yl[s] = V(0);
-    }
-    for (int s = nown + tid; s < nslots; s += BLOCK) {
-      xl[s] = x[d.halo_col[t.halo_off + (s - nown)]];
-      yl[s] = V(0);
-    }
-    __syncthreads();
-
     const V *tv = d.vals + t.nnz_off;
     const uint16_t *ts = d.slots + t.nnz_off;
-    for (int s = wave; s < t.nslices; s += NW) {
-      const int p = s * 64 + lane;
-      const bool has = p < nown;
-      const uint32_t info = has ? d.rowinfo[lrow0 + p] : 0u;
-      const int r = info & 0xffffu;
-      const int len = (int)(info >> 16);
-      const V dg = has ? d.diag[lrow0 + p] : V(0);
-      const V xi = xl[r];
-      V acc = V(0);
-      uint32_t off = d.slice_off[t.slice_base + s];
-      const int minlen = __builtin_amdgcn_readlane(len, 63);
-      const int maxlen = __builtin_amdgcn_readfirstlane(len);
-      const int nfull = minlen >> 2;
+    const uint2 *smeta = d.slice_meta + t.slice_base;
+    const int nsl = t.nslices;
 
-      for (int q = 0; q < nfull; ++q) {
-        V v[4];
-        load_packet(tv, off, lane, v);
-        const ushort4 c = *reinterpret_cast<const ushort4 *>(ts + off + lane * 4);
-        const unsigned cs[4] = {c.x, c.y, c.z, c.w};
+    // the matrix stream does not depend on x: request this wave's first slice
+    // header and head packet (and its first COO packet) before touching the LDS
+    // windows.  Slice metadata are scalar loads kept two slices ahead.
+    int s = wave;
+    uint2 meta_c = make_uint2(0u, 0u), meta_n = make_uint2(0u, 0u);
+    uint32_t info_c = 0u;
+    V dg_c = V(0);
+    Pkt<V> N;
+    N.v[0] = N.v[1] = N.v[2] = N.v[3] = V(0);
+    N.c = make_ushort4(0, 0, 0, 0);
+    if (s < nsl) {
+      meta_c = smeta[s];
+      if (s + NW < nsl) meta_n = smeta[s + NW];
+      const int p0 = s * 64 + lane, q0 = min(p0, nown - 1);
+      const uint32_t i0 = d.rowinfo[lrow0 + q0]; // unconditional, clamped
+      const V d0 = d.diag[lrow0 + q0];
+      info_c = p0 < nown ? i0 : 0u;
+      dg_c = p0 < nown ? d0 : V(0);
+      fetch_packet(N, tv, ts, meta_c.x, (int)meta_c.y, lane);
+    }
+    const int ncp = (t.ncoo + 255) >> 8; // COO packets of this tile
+    Pkt<V> C;
+    ushort4 Cr = make_ushort4(0, 0, 0, 0);
+    C.v[0] = C.v[1] = C.v[2] = C.v[3] = V(0);
+    C.c = Cr;
+    if (wave < ncp) {
+      fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)wave * 256u, 64, lane);
+      Cr = *reinterpret_cast<const ushort4 *>(d.crows + t.coo_off + wave * 256 + lane * 4);
+    }
+    // flush the previous tile's y window and refill both windows.  A thread
+    // owns the same slot indices in both steps, so no barrier is needed between.
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc = fma(v[j], xl[cs[j]], acc);
-          atomicAdd(&yl[cs[j]], v[j] * xi);
-        }
-        off += 256;
+    for (int k = 0; k < U; ++k) {
+      const int i = tid + k * BLOCK;
+      if (MODE != 4) {
+        if (i < prev_nown) y[prev_lrow0 + i] = yl[i];
+        else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = yl[i];
       }
-      for (int k = nfull << 2; k < maxlen; ++k) {
-        const bool act = k < len;
-        const unsigned long long m = __ballot(act);
-        if (act) {
-          const V v = tv[off + lane];
-          const unsigned c = ts[off + lane];
-          acc = fma(v, xl[c], acc);
-          atomicAdd(&yl[c], v * xi);
-        }
-        off += __popcll(m);
+      if (i < nslots) {
+        xl[i] = xr[k];
+        yl[i] = V(0);
       }
-      if (has) atomicAdd(&yl[r], fma(dg, xi, acc));
     }
     __syncthreads();
 
-    for (int s = tid; s < nown; s += BLOCK) y[lrow0 + s] = yl[s];
-    for (int s = nown + tid; s < nslots; s += BLOCK)
-      d.strip[t.halo_off + (s - nown)] = yl[s];
+    for (; MODE != 3 && s < nsl; s += NW) {
+      const uint32_t info = info_c;
+      const V dg = dg_c;
+      uint32_t off = meta_c.x;
+      int cnt = (int)meta_c.y;
+      Pkt<V> A = N;
+      const bool have_next = s + NW < nsl;
+      if (have_next) { // next slice: header + head packet, a whole slice ahead
+        const int pn = (s + NW) * 64 + lane, qn = min(pn, nown - 1);
+        const uint32_t in_ = d.rowinfo[lrow0 + qn]; // unconditional, clamped
+        const V dn = d.diag[lrow0 + qn];
+        info_c = pn < nown ? in_ : 0u;
+        dg_c = pn < nown ? dn : V(0);
+        fetch_packet(N, tv, ts, meta_n.x, (int)meta_n.y, lane);
+      }
+      meta_c = meta_n;
+      if (s + 2 * NW < nsl) meta_n = smeta[s + 2 * NW];
+
+      const int r = info & 0xffffu;
+      const int a = (int)(info >> 16); // packets of this lane's row
+      const V xi = xl[r];
+      V acc = V(0);
+      const int amax = __builtin_amdgcn_readfirstlane(a); // rows are sorted: lane 0 is longest
+
+      int g = 0;
+      Pkt<V> B;
+      while (g + 2 < amax) { // steady state: two packets per trip, no copies
+        const int cnt1 = __popcll(__ballot(a > g + 1));
+        const uint32_t off1 = off + 4u * (uint32_t)cnt;
+        fetch_packet(B, tv, ts, off1, cnt1, lane);
+        if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
+        const int cnt2 = __popcll(__ballot(a > g + 2));
+        const uint32_t off2 = off1 + 4u * (uint32_t)cnt1;
+        fetch_packet(A, tv, ts, off2, cnt2, lane);
+        if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
+        g += 2;
+        off = off2;
+        cnt = cnt2;
+      }
+      if (amax - g == 2) {
+        const int cnt1 = __popcll(__ballot(a > g + 1));
+        fetch_packet(B, tv, ts, off + 4u * (uint32_t)cnt, cnt1, lane);
+        if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
+        if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
+      } else if (amax - g == 1) {
+        if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
+      }
+      if (s * 64 + lane < nown) atomicAdd(&yl[r], fma(dg, xi, acc));
+    }
+    // COO leftovers: packet p = wave, wave + NW, ...; the first one was requested
+    // at the top of the tile
+    for (int cp = wave; MODE != 3 && cp < ncp; cp += NW) {
+      const Pkt<V> Q = C;
+      const ushort4 Qr = Cr;
+      if (cp + NW < ncp) {
+        fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)(cp + NW) * 256u, 64, lane);
+        Cr = *reinterpret_cast<const ushort4 *>(d.crows + t.coo_off + (cp + NW) * 256 + lane * 4);
+      }
+      const int e0 = cp * 256 + lane * 4;
+      if (e0 + 0 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[0], Qr.x, Q.c.x);
+      if (e0 + 1 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[1], Qr.y, Q.c.y);
+      if (e0 + 2 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[2], Qr.z, Q.c.z);
+      if (e0 + 3 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[3], Qr.w, Q.c.w);
+    }
+    if (ti + 1 < t1) gather_x(d.tiles[ti + 1]); // lands behind the barrier + flush
+    prev_nown = nown;
+    prev_nslots = nslots;
+    prev_lrow0 = lrow0;
+    prev_halo_off = t.halo_off;
     __syncthreads();
+  }
+  // flush the last tile
+#pragma unroll
+  for (int k = 0; k < U; ++k) {
+    const int i = tid + k * BLOCK;
+    if (MODE == 4) break;
+    if (i < prev_nown) y[prev_lrow0 + i] = yl[i];
+    else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = yl[i];
   }
 }
 
@@ -240,7 +425,7 @@ struct DevBuf {
 struct cfs_hip_sym_s {
   int value_bytes = 8;
   virtual ~cfs_hip_sym_s() {}
-  virtual int spmv_local(void *y, const void *x, void *send, hipStream_t st) = 0;
+  virtual int spmv_local(void *y, const void *x, void *send, hipStream_t st, int phases = 3) = 0;
   virtual int recv_fold(void *y, const void *recv, hipStream_t st) = 0;
   virtual int set_recv(int nrecv, const int *rows) = 0;
   virtual void stats(cfs_hip_sym_stats *o) = 0;
@@ -254,13 +439,15 @@ struct cfs_hip_sym_s {
 
 template <typename V> struct SymMatrix : cfs_hip_sym_s {
   SymPlan<V> P; // big arrays released after upload
-  DevBuf tiles, group_ptr, halo_col, rowinfo, diag, slice_off, vals, slots, strip;
+  DevBuf tiles, group_ptr, halo_col, rowinfo, diag, slice_meta, vals, slots, strip;
+  DevBuf cvals, crows, ccols;
   DevBuf fold_row, fold_ptr, fold_idx, send_ptr, send_idx;
   DevBuf rfold_row, rfold_ptr, rfold_idx;
   SymDev<V> dev{};
   int nfold = 0, nsend = 0, nrfold = 0;
+  int ablate_mode = 0; // cfs_hip_options.flags & 3 (timing-only ablations)
   size_t lds_bytes = 0;
-  int64_t halo_slots = 0, stream_len = 0, nslices = 0;
+  int64_t halo_slots = 0, stream_len = 0, nslices = 0, coo_len = 0;
 
   int upload() {
     int rc;
@@ -271,7 +458,10 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(halo_col, P.halo_col)
     UP(rowinfo, P.rowinfo)
     UP(diag, P.diag)
-    UP(slice_off, P.slice_off)
+    UP(slice_meta, P.slice_meta)
+    UP(cvals, P.cvals)
+    UP(crows, P.crows)
+    UP(ccols, P.ccols)
     UP(vals, P.vals)
     UP(slots, P.slots)
     UP(fold_row, P.fold_row)
@@ -280,10 +470,11 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(send_ptr, P.send_ptr)
     UP(send_idx, P.send_idx)
 #undef UP
-    if ((rc = strip.alloc(P.halo_col.size() * sizeof(V)))) return rc;
-    halo_slots = (int64_t)P.halo_col.size();
+    if ((rc = strip.alloc((size_t)P.nhalo * sizeof(V)))) return rc;
+    halo_slots = P.nhalo;
     stream_len = P.stream_len;
-    nslices = (int64_t)P.slice_off.size();
+    nslices = (int64_t)P.slice_meta.size();
+    coo_len = P.coo_len;
     nfold = (int)P.fold_row.size();
     nsend = (int)P.send_row.size();
     dev.tiles = (const Tile *)tiles.p;
@@ -291,7 +482,10 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     dev.halo_col = (const int32_t *)halo_col.p;
     dev.rowinfo = (const uint32_t *)rowinfo.p;
     dev.diag = (const V *)diag.p;
-    dev.slice_off = (const uint32_t *)slice_off.p;
+    dev.slice_meta = (const uint2 *)slice_meta.p;
+    dev.cvals = (const V *)cvals.p;
+    dev.crows = (const uint16_t *)crows.p;
+    dev.ccols = (const uint16_t *)ccols.p;
     dev.vals = (const V *)vals.p;
     dev.slots = (const uint16_t *)slots.p;
     dev.strip = (V *)strip.p;
@@ -301,6 +495,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     // release the big host arrays; keep the small metadata
     std::vector<V>().swap(P.vals);
     std::vector<uint16_t>().swap(P.slots);
+    std::vector<V>().swap(P.cvals);
+    std::vector<uint16_t>().swap(P.crows);
+    std::vector<uint16_t>().swap(P.ccols);
     std::vector<V>().swap(P.diag);
     std::vector<uint32_t>().swap(P.rowinfo);
     std::vector<int32_t>().swap(P.fold_idx);
@@ -309,9 +506,16 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   }
 
   template <int BLOCK> int raise_one() {
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 0>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 1>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 2>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 3>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 4>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return 0;
   }
   int raise_lds_limit() {
@@ -323,18 +527,48 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   }
 
   template <int BLOCK> void launch_tiles(V *y, const V *x, hipStream_t st) {
-    hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK>), dim3(P.ngroups), dim3(BLOCK),
-                       lds_bytes, st, dev, x, y);
+    const int mode = ablate_mode;
+    if (mode == 1)
+      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 1>), dim3(P.ngroups), dim3(BLOCK),
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+    else if (mode == 2)
+      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 2>), dim3(P.ngroups), dim3(BLOCK),
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+    else if (mode == 3)
+      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 3>), dim3(P.ngroups), dim3(BLOCK),
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+    else if (mode == 4)
+      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 4>), dim3(P.ngroups), dim3(BLOCK),
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+    else
+      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 0>), dim3(P.ngroups), dim3(BLOCK),
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
   }
 
-  int spmv_local(void *yv, const void *xv, void *sendv, hipStream_t st) override {
+  int spmv_local(void *yv, const void *xv, void *sendv, hipStream_t st, int phases) override {
     V *y = (V *)yv;
     const V *x = (const V *)xv;
     if (P.tiles.empty()) return 0;
-    switch (P.block_threads) {
-    case 256: launch_tiles<256>(y, x, st); break;
-    case 512: launch_tiles<512>(y, x, st); break;
-    default: launch_tiles<1024>(y, x, st); break;
+    if (phases & CFS_HIP_PHASE_TILES) {
+      switch (P.block_threads) {
+      case 256: launch_tiles<256>(y, x, st); break;
+      case 512: launch_tiles<512>(y, x, st); break;
+      default: launch_tiles<1024>(y, x, st); break;
+      }
+    }
+    if (!(phases & CFS_HIP_PHASE_FOLD)) {
+      HIPCHK(hipGetLastError());
+      return 0;
     }
     if (nfold > 0)
       hipLaunchKernelGGL((cfs_fold_kernel<V>), dim3((nfold + 255) / 256), dim3(256), 0,
@@ -391,13 +625,13 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     o->remote_vals = nsend;
     o->lds_bytes = (int64_t)lds_bytes;
     o->bytes_algorithmic = P.nnz_low * (4 + s) + rows_ * (4 + 3 * s);
-    o->bytes_streamed = stream_len * (s + 2) + rows_ * (4 + 3 * s) +
+    o->bytes_streamed = stream_len * (s + 2) + coo_len * (s + 4) + rows_ * (4 + 3 * s) +
                         halo_slots * (4 + 2 * s)            /* halo_col, x, strip st */
                         + halo_slots * (4 + s)              /* fold: idx + strip ld  */
-                        + (int64_t)(nfold + nsend) * (8 + 2 * s) + nslices * 4 +
+                        + (int64_t)(nfold + nsend) * (8 + 2 * s) + nslices * 8 +
                         (int64_t)P.tiles.size() * (int64_t)sizeof(Tile);
     o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + halo_col.bytes +
-                                rowinfo.bytes + diag.bytes + slice_off.bytes + vals.bytes +
+                                rowinfo.bytes + diag.bytes + slice_meta.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +
                                 slots.bytes + strip.bytes + fold_row.bytes + fold_ptr.bytes +
                                 fold_idx.bytes + send_ptr.bytes + send_idx.bytes);
   }
@@ -529,6 +763,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     delete m;
     return rc;
   }
+  m->ablate_mode = opt ? (opt->flags & CFS_HIP_FLAG_ABLATE_MASK) : 0;
   *out = m;
   return 0;
 }
@@ -628,6 +863,11 @@ int cfs_hip_sym_spmv_local_async(cfs_hip_sym_t h, void *y, const void *x, void *
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
   return h->spmv_local(y, x, send, (hipStream_t)stream);
 }
+int cfs_hip_sym_spmv_phases_async(cfs_hip_sym_t h, void *y, const void *x, void *send,
+                                  int phases, void *stream) {
+  if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  return h->spmv_local(y, x, send, (hipStream_t)stream, phases);
+}
 int cfs_hip_sym_recv_fold_async(cfs_hip_sym_t h, void *y, const void *recv, void *stream) {
   if (!h || !y) return set_err(CFS_HIP_ERR_ARG, "null argument");
   return h->recv_fold(y, recv, (hipStream_t)stream);
@@ -655,8 +895,8 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   cfs_plan::decode_plan(P, r, c, v);
   rep->ntiles = (int)P.tiles.size();
   rep->ngroups = P.ngroups;
-  rep->nslices = (int64_t)P.slice_off.size();
-  rep->halo_slots = (int64_t)P.halo_col.size();
+  rep->nslices = (int64_t)P.slice_meta.size();
+  rep->halo_slots = P.nhalo;
   rep->stream_len = P.stream_len;
   rep->nnz_low = P.nnz_low;
   rep->lds_slots = P.lds_slots;
@@ -693,7 +933,7 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   // (2) fold + send indices cover every strip entry exactly once and point at
   // a strip entry whose column is the destination row
   {
-    std::vector<char> seen(P.halo_col.size(), 0);
+    std::vector<char> seen((size_t)P.nhalo, 0);
     for (size_t i = 0; i < P.fold_row.size(); i++)
       for (int q = P.fold_ptr[i]; q < P.fold_ptr[i + 1]; q++) {
         int s = P.fold_idx[q];
@@ -734,6 +974,25 @@ int cfs_hip_sym_plan_check_f32(int n, const int *rowptr, const int *colind,
                                const int *row_splits, const cfs_hip_options *opt,
                                cfs_hip_plan_report *rep) {
   return plan_check<float>(n, rowptr, colind, values, nranks, rank, row_splits, opt, rep);
+}
+
+int cfs_hip_sym_plan_send_info_f64(int n, const int *rowptr, const int *colind,
+                                   const double *values, int nranks, int rank,
+                                   const int *row_splits, const cfs_hip_options *opt,
+                                   int *send_counts, int *rows, int rows_cap,
+                                   int *nrows_out) {
+  if (!send_counts || !nrows_out || !row_splits) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  SymPlan<double> P;
+  if (!cfs_plan::build_plan<double>(n, rowptr, colind, values, nranks, rank, row_splits,
+                                    to_opts(opt), P))
+    return set_err(CFS_HIP_ERR_UNSUPPORTED, P.error);
+  for (int r = 0; r < nranks; r++) send_counts[r] = P.send_counts[r];
+  *nrows_out = (int)P.send_row.size();
+  if (rows) {
+    if (rows_cap < *nrows_out) return set_err(CFS_HIP_ERR_ARG, "rows_cap too small");
+    for (size_t i = 0; i < P.send_row.size(); i++) rows[i] = P.send_row[i];
+  }
+  return 0;
 }
 
 // ---- general CSR ------------------------------------------------------------

@@ -15,10 +15,13 @@
 //     (own rows first, then the sorted "halo" columns left of the tile), so
 //     the gather x[col] and the transposed update y[col] += a*x[row] both hit
 //     LDS (ds_read / ds_add), and the index stream shrinks from 4 to 2 bytes;
-//   * rows of a tile are sorted by length and stored in 64-row SLICES as
-//     jagged diagonals (lane l holds row l of the slice), the first
-//     4*floor(min_len/4) diagonals in 4-wide PACKETS laid out for 16-byte
-//     coalesced loads, the rest one diagonal at a time: zero padding entries;
+//   * rows of a tile are sorted by length and stored in 64-row SLICES (lane l
+//     holds row l of the slice) as a uniform stream of 4-diagonal PACKETS laid
+//     out for 16-byte coalesced loads; a packet covers the lanes whose row
+//     still has 4 more entries (a prefix of the lanes, because rows are
+//     sorted), so there is no padding and no special case in the stream.  The
+//     len%4 last entries of every row go to a small per-tile COO section
+//     (row slot, column slot, value) handled with LDS atomics on both sides;
 //   * conflicts BETWEEN tiles (the reference's direct conflicts, :1443-1451)
 //     are not coloured away but deferred: a tile stores its halo sums to a
 //     private strip with plain coalesced stores and a tiny second kernel folds
@@ -50,15 +53,24 @@ struct Tile {
   int32_t nslots;     // nown + halo slots
   int32_t nslices;    // ceil(nown / 64)
   int32_t halo_off;   // offset of this tile's halo in halo_col[] and strip[]
-  int32_t slice_base; // offset of this tile's slices in slice_off[]
-  int64_t nnz_off;    // offset of this tile's entries in vals[] / slots[]
+  int32_t slice_base; // offset of this tile's slices in slice_meta[]
+  int64_t nnz_off;    // offset of this tile's packet stream in vals[] / slots[]
+  int32_t coo_off;    // offset of this tile's COO section in cvals/crows/ccols
+  int32_t ncoo;       // leftover entries (len % 4 per row)
+  int32_t pad_[2];
 };
-static_assert(sizeof(Tile) == 32, "Tile must stay 32 bytes");
+static_assert(sizeof(Tile) == 48, "Tile must stay 48 bytes");
+
+struct SliceMeta {
+  uint32_t off;  // entry offset of the slice's first packet inside its tile
+  uint32_t cnt0; // lanes of that first packet (rows of the slice with >= 4 entries)
+};
 
 constexpr int kLanes = 64;
 constexpr int kPacket = 4;            // diagonals per packet
 constexpr int kAlignEntries = 8;      // slice streams start on 8-entry bounds
 constexpr int kMaxSlotsHard = 10240;  // 16 B/slot fp64 -> 160 KiB LDS
+constexpr int kSlotsPerThread = 10;   // LDS slots one thread fills/flushes (registers)
 
 template <typename V> struct SymPlan {
   // problem
@@ -71,11 +83,14 @@ template <typename V> struct SymPlan {
   std::vector<Tile> tiles;
   std::vector<int32_t> group_ptr;   // [ngroups+1] tiles of persistent group g
   std::vector<int32_t> halo_col;    // [H] global column of every halo slot
-  std::vector<uint32_t> rowinfo;    // [rows] sorted position -> local_row | len<<16
+  std::vector<uint32_t> rowinfo;    // [rows] sorted position -> local_row | npackets<<16
   std::vector<V> diag;              // [rows] diagonal, in sorted position order
-  std::vector<uint32_t> slice_off;  // [S] entry offset of a slice inside its tile
-  std::vector<V> vals;              // [stream_len]
-  std::vector<uint16_t> slots;      // [stream_len]
+  std::vector<SliceMeta> slice_meta; // [S]
+  std::vector<V> vals;              // [stream_len + pad] packet stream
+  std::vector<uint16_t> slots;      // [stream_len + pad]
+  std::vector<V> cvals;             // [coo_len] COO leftovers, packet layout
+  std::vector<uint16_t> crows, ccols; // [coo_len]
+  int64_t coo_len = 0, coo_entries = 0;
   // halo fold (destinations inside [row_begin,row_end)), local row indices
   std::vector<int32_t> fold_row, fold_ptr, fold_idx;
   // remote contributions (destinations < row_begin), global row indices
@@ -84,16 +99,18 @@ template <typename V> struct SymPlan {
   int nrecv = 0;
   std::vector<int32_t> rfold_row, rfold_ptr, rfold_idx;
   int64_t stream_len = 0;
+  int64_t nhalo = 0; // halo slots (halo_col carries one extra padding entry)
   std::string error;
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
-// Position of entry (packet g, lane l, diagonal j of the packet) inside a
-// packet's 256 entries.  Values: two fully contiguous 16-byte-per-lane loads
-// for fp64 ([half][lane][2]), one for fp32 ([lane][4]).  Slots: [lane][4].
-template <typename V> inline int packet_val_pos(int l, int j) {
-  if (sizeof(V) == 8) return (j >> 1) * 128 + l * 2 + (j & 1);
+// Position of entry (lane l, diagonal j of the packet) inside a packet that
+// covers `cnt` lanes (4*cnt entries).  Values: two fully contiguous
+// 16-byte-per-lane loads for fp64 ([half][lane][2]), one for fp32 ([lane][4]).
+// Slots: [lane][4].
+template <typename V> inline int packet_val_pos(int l, int j, int cnt = 64) {
+  if (sizeof(V) == 8) return (j >> 1) * 2 * cnt + l * 2 + (j & 1);
   return l * 4 + j;
 }
 inline int packet_slot_pos(int l, int j) { return l * 4 + j; }
@@ -156,6 +173,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
     return false;
   }
   P.block_threads = block;
+  if (max_slots > kSlotsPerThread * block) max_slots = kSlotsPerThread * block;
+  P.max_slots = max_slots;
   const int64_t max_tile_nnz =
       opt.max_tile_nnz > 0 ? opt.max_tile_nnz : (int64_t)1 << 30;
 
@@ -176,51 +195,103 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
   P.nnz_diag = nnz_diag;
   P.nnz_full = 2 * nnz_low + nnz_diag;
 
-  // ---- cut rows into tiles (sequential, O(nnz)) --------------------------
+  // ---- persistent groups first, tiles inside them ----------------------------
+  // A CU only streams ~1/256 of the HBM bandwidth, so the launch is as long as
+  // its most loaded CU: rows are first cut into `ngroups` contiguous chunks of
+  // equal streamed bytes (one chunk per persistent workgroup, as many
+  // workgroups as are co-resident), and only then into LDS-sized tiles that
+  // never straddle a chunk.
   {
+    const int64_t lds_budget = (int64_t)max_slots * slot_bytes;
+    int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / lds_budget, 2048 / block);
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    int ngroups = 256 * wg_per_cu;
+    int by_rows = ((rows + 63) / 64 + 7) / 8 * 8;
+    if (ngroups > by_rows) ngroups = by_rows;
+    if (ngroups < 8) ngroups = 8;
+    P.ngroups = ngroups;
+    std::vector<int64_t> cost(rows + 1, 0);
+    for (int r = 0; r < rows; r++)
+      cost[r + 1] = cost[r] + (int64_t)lcnt[r] * (int64_t)(sizeof(V) + 2) +
+                    (int64_t)(4 + 3 * sizeof(V)) + 2 * (int64_t)sizeof(V);
+    std::vector<int32_t> chunk(ngroups + 1, re);
+    chunk[0] = rb;
+    for (int g = 1; g < ngroups; g++) {
+      int64_t target = cost[rows] * g / ngroups;
+      int r = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
+      if (r > rows) r = rows;
+      if (rb + r < chunk[g - 1]) r = chunk[g - 1] - rb;
+      chunk[g] = rb + r;
+    }
+    chunk[ngroups] = re;
+
     std::vector<int32_t> stamp(n > 0 ? n : 1, -1);
-    int row = rb, tid = 0;
-    while (row < re) {
-      Tile t{};
-      t.row0 = row;
-      int nown = 0, nhalo = 0;
-      int64_t nnz = 0;
-      while (row < re) {
-        int newh = 0, len = 0;
-        for (int j = rowptr[row]; j < rowptr[row + 1]; j++) {
-          int c = colind[j];
-          if (c >= row) continue;
-          len++;
-          if (c < t.row0 && stamp[c] != tid) {
-            stamp[c] = tid;
-            newh++;
+    int tid = 0;
+    // greedy cut of rows [r0, r1) under the slot budget and a cost cap; returns
+    // false on an unschedulable row
+    auto cut = [&](int r0, int r1, int64_t cap, std::vector<Tile> &out) -> bool {
+      int row = r0;
+      while (row < r1) {
+        Tile t{};
+        t.row0 = row;
+        int nown = 0, nhalo = 0;
+        int64_t nnz = 0, c0 = cost[row - rb];
+        while (row < r1) {
+          int newh = 0, len = 0;
+          for (int j = rowptr[row]; j < rowptr[row + 1]; j++) {
+            int c = colind[j];
+            if (c >= row) continue;
+            len++;
+            if (c < t.row0 && stamp[c] != tid) {
+              stamp[c] = tid;
+              newh++;
+            }
           }
-        }
-        if (len > 65535) {
-          P.error = "row with more than 65535 lower entries";
-          return false;
-        }
-        bool fits = (nown + 1 + nhalo + newh <= max_slots) &&
-                    (nnz + len <= max_tile_nnz || nown == 0) && nown < 65535;
-        if (!fits) {
-          if (nown == 0) {
-            P.error = "a single row needs more LDS slots than max_slots "
-                      "(dense row): unsupported by the tile schedule";
+          if (len > 65535) {
+            P.error = "row with more than 65535 lower entries";
             return false;
           }
-          break; // stale stamps are harmless: the next tile uses tid + 1
+          bool fits = (nown + 1 + nhalo + newh <= max_slots) &&
+                      (nnz + len <= max_tile_nnz || nown == 0) && nown < 65535 &&
+                      (cost[row + 1 - rb] - c0 <= cap || nown == 0);
+          if (!fits) {
+            if (nown == 0) {
+              P.error = "a single row needs more LDS slots than max_slots "
+                        "(dense row): unsupported by the tile schedule";
+              return false;
+            }
+            break; // stale stamps are harmless: the next tile uses tid + 1
+          }
+          nown++;
+          nhalo += newh;
+          nnz += len;
+          row++;
         }
-        nown++;
-        nhalo += newh;
-        nnz += len;
-        row++;
+        t.nown = nown;
+        t.nslots = nown + nhalo;
+        t.nslices = (nown + kLanes - 1) / kLanes;
+        out.push_back(t);
+        tid++;
       }
-      t.nown = nown;
-      t.nslots = nown + nhalo;
-      t.nslices = (nown + kLanes - 1) / kLanes;
-      P.tiles.push_back(t);
-      tid++;
+      return true;
+    };
+    P.group_ptr.assign(ngroups + 1, 0);
+    std::vector<Tile> tmp;
+    for (int g = 0; g < ngroups; g++) {
+      const int r0 = chunk[g], r1 = chunk[g + 1];
+      P.group_ptr[g] = (int32_t)P.tiles.size();
+      if (r0 >= r1) continue;
+      tmp.clear();
+      if (!cut(r0, r1, (int64_t)1 << 60, tmp)) return false;
+      if (tmp.size() > 1) { // even the tiles of a chunk out (less halo, same count)
+        const int64_t cc = cost[r1 - rb] - cost[r0 - rb];
+        std::vector<Tile> even;
+        if (!cut(r0, r1, cc / (int64_t)tmp.size() + cc / 64 + 1, even)) return false;
+        if (even.size() <= tmp.size()) tmp.swap(even);
+      }
+      P.tiles.insert(P.tiles.end(), tmp.begin(), tmp.end());
     }
+    P.group_ptr[ngroups] = (int32_t)P.tiles.size();
   }
   const int T = (int)P.tiles.size();
 
@@ -237,57 +308,85 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
         return false;
       }
     }
-    P.halo_col.assign((size_t)halo, 0);
-    P.slice_off.assign((size_t)slices, 0);
+    P.nhalo = halo;
+    P.halo_col.assign((size_t)halo + 1, 0); // +1: the kernel's clamped dummy read
+    P.slice_meta.assign((size_t)slices, SliceMeta{0u, 0u});
     P.rowinfo.assign((size_t)rows, 0);
     P.diag.assign((size_t)rows, V(0));
   }
 
-  // ---- per tile: halo map, length sort, stream sizes ------------------------
-  // pass A computes per-tile stream length and slice offsets, pass B fills.
+  // ---- per tile: length sort, stream sizes, then fill -------------------------
   std::vector<int64_t> tile_len(T, 0);
-  std::vector<std::vector<int32_t>> perm_store; // not kept: recomputed in pass B
-  (void)perm_store;
+  // stable counting sort of a tile's local rows by packet count (len / 4),
+  // descending: the lanes still active in packet g are then a prefix
   auto sort_rows = [&](const Tile &t, std::vector<int32_t> &perm) {
-    // stable counting sort of local rows by lower length, descending
     perm.resize(t.nown);
-    int maxlen = 0;
+    int maxa = 0;
     for (int r = 0; r < t.nown; r++)
-      maxlen = std::max(maxlen, (int)lcnt[t.row0 - rb + r]);
-    std::vector<int32_t> cnt(maxlen + 2, 0);
-    for (int r = 0; r < t.nown; r++) cnt[maxlen - lcnt[t.row0 - rb + r] + 1]++;
-    for (int k = 0; k <= maxlen; k++) cnt[k + 1] += cnt[k];
-    for (int r = 0; r < t.nown; r++) perm[cnt[maxlen - lcnt[t.row0 - rb + r]]++] = r;
+      maxa = std::max(maxa, (int)lcnt[t.row0 - rb + r] >> 2);
+    std::vector<int32_t> cnt(maxa + 2, 0);
+    for (int r = 0; r < t.nown; r++) cnt[maxa - (lcnt[t.row0 - rb + r] >> 2) + 1]++;
+    for (int k = 0; k <= maxa; k++) cnt[k + 1] += cnt[k];
+    for (int r = 0; r < t.nown; r++) perm[cnt[maxa - (lcnt[t.row0 - rb + r] >> 2)]++] = r;
   };
 #pragma omp parallel for schedule(dynamic, 8)
   for (int ti = 0; ti < T; ti++) {
-    const Tile &t = P.tiles[ti];
+    Tile &t = P.tiles[ti];
     std::vector<int32_t> perm;
     sort_rows(t, perm);
-    int64_t off = 0;
+    int64_t off = 0, left = 0;
     for (int s = 0; s < t.nslices; s++) {
       off = align_up(off, kAlignEntries);
-      P.slice_off[t.slice_base + s] = (uint32_t)off;
       int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nown);
-      for (int p = p0; p < p1; p++) off += lcnt[t.row0 - rb + perm[p]];
+      uint32_t cnt0 = 0;
+      for (int p = p0; p < p1; p++) {
+        int len = lcnt[t.row0 - rb + perm[p]];
+        off += (int64_t)(len >> 2) * 4;
+        left += len & 3;
+        if (len >= 4) cnt0++;
+      }
+      // meta.off is set below (needs the offset BEFORE this slice's entries)
+      P.slice_meta[t.slice_base + s].cnt0 = cnt0;
+    }
+    // second walk for the offsets (kept separate for clarity)
+    off = 0;
+    for (int s = 0; s < t.nslices; s++) {
+      off = align_up(off, kAlignEntries);
+      P.slice_meta[t.slice_base + s].off = (uint32_t)off;
+      int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nown);
+      for (int p = p0; p < p1; p++) off += (int64_t)(lcnt[t.row0 - rb + perm[p]] >> 2) * 4;
     }
     tile_len[ti] = align_up(off, kAlignEntries);
+    t.ncoo = (int32_t)left;
   }
   {
-    int64_t off = 0;
+    int64_t off = 0, coo = 0;
     for (int ti = 0; ti < T; ti++) {
       P.tiles[ti].nnz_off = off;
       off += tile_len[ti];
+      P.tiles[ti].coo_off = (int32_t)coo;
+      P.coo_entries += P.tiles[ti].ncoo;
+      coo += align_up(P.tiles[ti].ncoo, 256);
+      if (coo > 0x7fffff00LL) {
+        P.error = "COO section overflow";
+        return false;
+      }
     }
     P.stream_len = off;
-    P.vals.assign((size_t)off, V(0));
-    P.slots.assign((size_t)off, 0);
+    P.coo_len = coo;
+    // one packet of padding: the kernel prefetches a slice's first packet with
+    // every lane before it knows how many lanes the packet really has
+    P.vals.assign((size_t)off + 256, V(0));
+    P.slots.assign((size_t)off + 256, 0);
+    P.cvals.assign((size_t)coo + 256, V(0));
+    P.crows.assign((size_t)coo + 256, 0);
+    P.ccols.assign((size_t)coo + 256, 0);
   }
   bool dup_error = false;
 #pragma omp parallel
   {
     std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
-    std::vector<int32_t> perm, hcols;
+    std::vector<int32_t> perm, hcols, lowj;
 #pragma omp for schedule(dynamic, 8)
     for (int ti = 0; ti < T; ti++) {
       const Tile &t = P.tiles[ti];
@@ -309,94 +408,80 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
         colmap[hcols[h]] = t.nown + (int)h;
         P.halo_col[t.halo_off + h] = hcols[h];
       }
+      auto slot_of = [&](int c) {
+        return (uint16_t)(c >= t.row0 ? c - t.row0 : colmap[c]);
+      };
+      // positions (in the full CSR) of the lower entries of local row r, in
+      // stored order -- works whether or not the columns of a row ascend
+      auto lower_of = [&](int r, std::vector<int32_t> &out) {
+        out.clear();
+        int i = t.row0 + r;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+          if (colind[j] < i) out.push_back(j);
+      };
       sort_rows(t, perm);
       V *tv = P.vals.data() + t.nnz_off;
       uint16_t *ts = P.slots.data() + t.nnz_off;
-      std::vector<int32_t> start(kLanes), len(kLanes);
+      std::vector<std::vector<int32_t>> low(kLanes);
       for (int s = 0; s < t.nslices; s++) {
         int p0 = s * kLanes, m = std::min(kLanes, (int)t.nown - p0);
+        int amax = 0;
         for (int l = 0; l < m; l++) {
           int r = perm[p0 + l], i = t.row0 + r;
-          len[l] = lcnt[i - rb];
-          P.rowinfo[t.row0 - rb + p0 + l] = (uint32_t)r | ((uint32_t)len[l] << 16);
-          // first lower entry of row i; the lower entries are a prefix of the
-          // row because columns ascend (csr_matrix.tpp:74-107)
-          start[l] = rowptr[i];
+          lower_of(r, low[l]);
+          int a = (int)low[l].size() >> 2;
+          amax = std::max(amax, a);
+          P.rowinfo[t.row0 - rb + p0 + l] = (uint32_t)r | ((uint32_t)a << 16);
           V d = V(0);
           for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
             if (colind[j] == i) d = values[j]; // last duplicate wins, like :1292
           P.diag[t.row0 - rb + p0 + l] = d;
         }
-        auto entry = [&](int l, int k, V &v, uint16_t &sl) {
-          // k-th lower entry of the row held by lane l.  Rows are scanned
-          // rather than assumed prefix-ordered, so unsorted input still works.
-          int i = t.row0 + perm[p0 + l], seen = 0;
-          for (int j = start[l]; j < rowptr[i + 1]; j++) {
-            if (colind[j] >= i) continue;
-            if (seen == k) {
-              int c = colind[j];
-              v = values[j];
-              sl = (uint16_t)(c >= t.row0 ? c - t.row0 : colmap[c]);
-              return;
-            }
-            seen++;
-          }
-        };
-        int64_t base = P.slice_off[t.slice_base + s];
-        int minlen = (m == kLanes) ? len[kLanes - 1] : 0;
-        int nfull = minlen / kPacket;
-        // fast path: columns ascend, so the k-th lower entry is rowptr[i]+k
-        bool prefix = true;
-        for (int l = 0; l < m && prefix; l++) {
-          int i = t.row0 + perm[p0 + l];
-          for (int k = 0; k < len[l]; k++)
-            if (colind[rowptr[i] + k] >= i) {
-              prefix = false;
-              break;
-            }
-        }
-        auto fetch = [&](int l, int k, V &v, uint16_t &sl) {
-          if (prefix) {
-            int i = t.row0 + perm[p0 + l];
-            int j = rowptr[i] + k, c = colind[j];
-            v = values[j];
-            sl = (uint16_t)(c >= t.row0 ? c - t.row0 : colmap[c]);
-          } else {
-            entry(l, k, v, sl);
-          }
-        };
-        for (int g = 0; g < nfull; g++)
-          for (int l = 0; l < kLanes; l++)
+        int64_t o = P.slice_meta[t.slice_base + s].off;
+        for (int g = 0; g < amax; g++) {
+          int cnt = 0;
+          while (cnt < m && ((int)low[cnt].size() >> 2) > g) cnt++;
+          for (int l = 0; l < cnt; l++)
             for (int j = 0; j < kPacket; j++) {
-              V v;
-              uint16_t sl;
-              fetch(l, g * kPacket + j, v, sl);
-              tv[base + (int64_t)g * 256 + packet_val_pos<V>(l, j)] = v;
-              ts[base + (int64_t)g * 256 + packet_slot_pos(l, j)] = sl;
+              int q = low[l][g * kPacket + j];
+              tv[o + packet_val_pos<V>(l, j, cnt)] = values[q];
+              ts[o + packet_slot_pos(l, j)] = slot_of(colind[q]);
             }
-        int64_t o = base + (int64_t)nfull * 256;
-        int maxlen = m > 0 ? len[0] : 0;
-        for (int k = nfull * kPacket; k < maxlen; k++)
-          for (int l = 0; l < m && len[l] > k; l++) {
-            V v;
-            uint16_t sl;
-            fetch(l, k, v, sl);
-            tv[o] = v;
-            ts[o] = sl;
-            o++;
+          o += 4 * (int64_t)cnt;
+        }
+      }
+      // COO leftovers: the last len%4 lower entries of every row, natural row
+      // order, in 256-entry packets with the packet value layout
+      {
+        V *cv = P.cvals.data() + t.coo_off;
+        uint16_t *cr = P.crows.data() + t.coo_off, *cc = P.ccols.data() + t.coo_off;
+        int64_t e = 0;
+        for (int r = 0; r < t.nown; r++) {
+          lower_of(r, lowj);
+          int len = (int)lowj.size();
+          for (int k = (len >> 2) << 2; k < len; k++) {
+            int q = lowj[k];
+            int64_t pk = e >> 8;
+            int l = (int)((e & 255) >> 2), j = (int)(e & 3);
+            cv[pk * 256 + packet_val_pos<V>(l, j)] = values[q];
+            cr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)r;
+            cc[pk * 256 + packet_slot_pos(l, j)] = slot_of(colind[q]);
+            e++;
           }
+        }
+        if (e != t.ncoo) dup_error = true;
       }
       for (int c : hcols) colmap[c] = -1;
     }
   }
   if (dup_error) {
-    P.error = "internal: halo count mismatch";
+    P.error = "internal: halo / leftover count mismatch";
     return false;
   }
 
   // ---- halo fold index: strips -> destination rows, fixed order --------------
   {
-    const int64_t H = (int64_t)P.halo_col.size();
+    const int64_t H = P.nhalo;
     std::vector<int32_t> lcount(rows + 1, 0), rcount(rb + 1, 0);
     for (int64_t q = 0; q < H; q++) {
       int c = P.halo_col[q];
@@ -436,38 +521,11 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
     }
   }
 
-  // ---- persistent groups: contiguous tiles, cost balanced ---------------------
+  // ---- LDS window: the largest tile decides --------------------------------
   {
     int lds_slots = 64;
     for (auto &t : P.tiles) lds_slots = std::max(lds_slots, (int)t.nslots);
     P.lds_slots = (lds_slots + 63) / 64 * 64;
-    int64_t lds_bytes = (int64_t)P.lds_slots * slot_bytes;
-    int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / lds_bytes, 2048 / block);
-    if (wg_per_cu < 1) wg_per_cu = 1;
-    int ngroups = 256 * wg_per_cu;
-    if (ngroups > T) ngroups = (T + 7) / 8 * 8;
-    if (ngroups < 8) ngroups = 8;
-    P.ngroups = ngroups;
-    std::vector<int64_t> cost(T + 1, 0);
-    for (int ti = 0; ti < T; ti++) {
-      const Tile &t = P.tiles[ti];
-      int64_t c = tile_len[ti] * (int64_t)(sizeof(V) + 2) +
-                  (int64_t)t.nown * (4 + 3 * sizeof(V)) +
-                  (int64_t)(t.nslots - t.nown) * (4 + 2 * sizeof(V)) + 512;
-      cost[ti + 1] = cost[ti] + c;
-    }
-    P.group_ptr.assign(ngroups + 1, T);
-    P.group_ptr[0] = 0;
-    for (int g = 1; g < ngroups; g++) {
-      int64_t target = cost[T] * g / ngroups;
-      int ti = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
-      // nearest boundary
-      if (ti > 0 && target - cost[ti - 1] < cost[ti] - target) ti--;
-      if (ti < P.group_ptr[g - 1]) ti = P.group_ptr[g - 1];
-      if (ti > T) ti = T;
-      P.group_ptr[g] = ti;
-    }
-    P.group_ptr[ngroups] = T;
   }
   return true;
 }
@@ -519,32 +577,44 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
     auto slot_col = [&](int s) {
       return s < t.nown ? t.row0 + s : P.halo_col[t.halo_off + (s - t.nown)];
     };
+    // per row: packet entries first (k = 0 .. 4a-1), then its COO leftovers, so
+    // that the decoded order inside a row equals the stored order
+    std::vector<std::vector<std::pair<int32_t, V>>> rows_out(t.nown);
     for (int s = 0; s < t.nslices; s++) {
       int p0 = s * kLanes, m = std::min(kLanes, (int)t.nown - p0);
-      int len[kLanes], r[kLanes];
+      int a[kLanes], r[kLanes];
       for (int l = 0; l < kLanes; l++) {
         uint32_t info = l < m ? P.rowinfo[t.row0 - rb + p0 + l] : 0;
         r[l] = info & 0xffff;
-        len[l] = info >> 16;
+        a[l] = info >> 16;
       }
-      int64_t base = P.slice_off[t.slice_base + s];
-      int minlen = len[kLanes - 1], nfull = minlen / kPacket;
-      for (int g = 0; g < nfull; g++)
-        for (int l = 0; l < kLanes; l++)
-          for (int j = 0; j < kPacket; j++) {
-            row.push_back(t.row0 + r[l]);
-            col.push_back(slot_col(ts[base + (int64_t)g * 256 + packet_slot_pos(l, j)]));
-            val.push_back(tv[base + (int64_t)g * 256 + packet_val_pos<V>(l, j)]);
-          }
-      int64_t o = base + (int64_t)nfull * 256;
-      for (int k = nfull * kPacket; k < len[0]; k++)
-        for (int l = 0; l < kLanes && len[l] > k; l++) {
-          row.push_back(t.row0 + r[l]);
-          col.push_back(slot_col(ts[o]));
-          val.push_back(tv[o]);
-          o++;
-        }
+      int64_t o = P.slice_meta[t.slice_base + s].off;
+      int amax = a[0];
+      for (int g = 0; g < amax; g++) {
+        int cnt = 0;
+        while (cnt < kLanes && a[cnt] > g) cnt++;
+        for (int l = 0; l < cnt; l++)
+          for (int j = 0; j < kPacket; j++)
+            rows_out[r[l]].push_back({slot_col(ts[o + packet_slot_pos(l, j)]),
+                                      tv[o + packet_val_pos<V>(l, j, cnt)]});
+        o += 4 * (int64_t)cnt;
+      }
     }
+    const V *cv = P.cvals.data() + t.coo_off;
+    const uint16_t *cr = P.crows.data() + t.coo_off, *cc = P.ccols.data() + t.coo_off;
+    for (int64_t e = 0; e < t.ncoo; e++) {
+      int64_t pk = e >> 8;
+      int l = (int)((e & 255) >> 2), j = (int)(e & 3);
+      rows_out[cr[pk * 256 + packet_slot_pos(l, j)]].push_back(
+          {slot_col(cc[pk * 256 + packet_slot_pos(l, j)]),
+           cv[pk * 256 + packet_val_pos<V>(l, j)]});
+    }
+    for (int rr = 0; rr < t.nown; rr++)
+      for (auto &e : rows_out[rr]) {
+        row.push_back(t.row0 + rr);
+        col.push_back(e.first);
+        val.push_back(e.second);
+      }
   }
 }
 

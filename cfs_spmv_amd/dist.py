@@ -1,0 +1,59 @@
+"""1-D row-block sharding of the symmetric SpMV over torch.distributed
+(one process per GPU; backend "nccl" is RCCL over xGMI on ROCm).
+
+SURVEY.md 8(e): rank g owns rows [R_g, R_{g+1}) (boundaries at multiples of 16,
+nnz_low-balanced), holds their strict-lower entries + diagonal and a full
+replica of x.  Row-side sums are local.  Transposed updates y_j += a_ij x_i with
+j < R_g are the reference's *direct conflicts* (csr_matrix.tpp:1443-1451); they
+are packed (one value per touched remote row) and exchanged in ONE collective.
+
+The north-star names a reduce-scatter of the off-block contributions.  A dense
+reduce-scatter would move n*s bytes per rank around a ring (~72 us for
+Flan_1565 over xGMI); the contributions only reach the previous
+block(s), so the exchange here is the sparse form of the same reduction: an
+all-to-all of exactly the touched rows, summed on the owner in a fixed order.
+"""
+import numpy as np
+
+
+class ShardedSym:
+    """backend: object with send_counts(), send_rows(), set_recv(rows),
+    spmv_local(y_block, x, send), recv_fold(y_block, recv), row_begin, row_end.
+    On a GPU box that is cfs_spmv_amd.SymMatrix; CPU tests pass a double."""
+
+    def __init__(self, backend, nranks, rank, dtype, device, pg=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.A, self.nranks, self.rank, self.pg = backend, nranks, rank, pg
+        self.device = device
+        tdt = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
+        send_counts = np.asarray(backend.send_counts(), dtype=np.int64)
+        send_rows = np.asarray(backend.send_rows(), dtype=np.int32)
+        assert send_counts.sum() == send_rows.size
+        # 1) counts
+        sc = torch.from_numpy(send_counts).to(device)
+        rc = torch.zeros(nranks, dtype=torch.int64, device=device)
+        dist.all_to_all_single(rc, sc, group=pg)
+        self.send_splits = [int(v) for v in send_counts]
+        self.recv_splits = [int(v) for v in rc.cpu().numpy()]
+        # 2) row lists (static): what will arrive where
+        nrecv = sum(self.recv_splits)
+        sr = torch.from_numpy(send_rows.astype(np.int32)).to(device)
+        rr = torch.zeros(nrecv, dtype=torch.int32, device=device)
+        dist.all_to_all_single(rr, sr, self.recv_splits, self.send_splits, group=pg)
+        backend.set_recv(rr.cpu().numpy())
+        self.send_buf = torch.zeros(max(1, send_rows.size), dtype=tdt, device=device)
+        self.recv_buf = torch.zeros(max(1, nrecv), dtype=tdt, device=device)
+        self.nsend, self.nrecv = int(send_rows.size), int(nrecv)
+
+    def spmv(self, y_block, x):
+        """y_block <- rows [row_begin,row_end) of A x; x is the full vector."""
+        self.A.spmv_local(y_block, x, self.send_buf)
+        self.exchange_and_fold(y_block)
+
+    def exchange_and_fold(self, y_block):
+        """the one collective of the path + the owner-side sum (fixed order)"""
+        self.dist.all_to_all_single(self.recv_buf[:self.nrecv], self.send_buf[:self.nsend],
+                                    self.recv_splits, self.send_splits, group=self.pg)
+        self.A.recv_fold(y_block, self.recv_buf)

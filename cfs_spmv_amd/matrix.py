@@ -78,6 +78,27 @@ def plan_check(n, rowptr, colind, values, nranks=1, rank=0, row_splits=None, opt
     return rep.asdict()
 
 
+def plan_send_info(n, rowptr, colind, values, nranks, rank, row_splits, options=None):
+    """host-only (send_counts, send_rows) of one shard -- for the CPU exchange tests"""
+    lib = _lib.load()
+    rowptr, colind = _np_i32(rowptr), _np_i32(colind)
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    rs = _np_i32(row_splits)
+    counts = np.zeros(nranks, dtype=np.int32)
+    nr = C.c_int()
+    optp = C.byref(options) if options is not None else None
+    _lib.check(lib.cfs_hip_sym_plan_send_info_f64(
+        n, rowptr.ctypes.data, colind.ctypes.data, values.ctypes.data, nranks, rank,
+        rs.ctypes.data, optp, counts.ctypes.data, None, 0, C.byref(nr)))
+    rows = np.zeros(nr.value, dtype=np.int32)
+    if nr.value:
+        _lib.check(lib.cfs_hip_sym_plan_send_info_f64(
+            n, rowptr.ctypes.data, colind.ctypes.data, values.ctypes.data, nranks, rank,
+            rs.ctypes.data, optp, counts.ctypes.data, rows.ctypes.data, nr.value,
+            C.byref(nr)))
+    return counts, rows
+
+
 class SymMatrix:
     """A symmetric matrix tuned for the MI355X tile kernel (Format::sss).
 
@@ -166,6 +187,12 @@ class SymMatrix:
         _lib.check(_lib.load().cfs_hip_sym_spmv_local_async(
             self._h, _ptr(y_block), _ptr(x), _ptr(send_buf) if send_buf is not None else None,
             _stream_ptr(stream)))
+
+    def spmv_phases(self, y_block, x, send_buf, phases, stream=None):
+        """enqueue only the selected launches (1 = tile kernel, 2 = halo fold/pack)"""
+        _lib.check(_lib.load().cfs_hip_sym_spmv_phases_async(
+            self._h, _ptr(y_block), _ptr(x), _ptr(send_buf) if send_buf is not None else None,
+            int(phases), _stream_ptr(stream)))
 
     def recv_fold(self, y_block, recv_buf, stream=None):
         _lib.check(_lib.load().cfs_hip_sym_recv_fold_async(

@@ -71,8 +71,14 @@ typedef struct {
   int max_slots;     /* LDS slots (x and y windows) per tile               */
   int max_tile_nnz;  /* cap on stored nonzeros per tile                    */
   int block_threads; /* workgroup size of the tile kernel: 256, 512, 1024  */
-  int flags;         /* reserved                                            */
+  int flags;         /* CFS_HIP_FLAG_*                                      */
 } cfs_hip_options;
+/* timing-only ablations of the tile kernel (WRONG results by construction;
+ * used by tools/ to price LDS atomics and LDS gathers against the pure matrix
+ * stream; never set by the product callers): 1 = no transposed LDS atomics,
+ * 2 = no LDS traffic at all, 3 = LDS windows only (no matrix stream),
+ * 4 = matrix stream only (no x gather / y flush)                             */
+#define CFS_HIP_FLAG_ABLATE_MASK 7
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->
@@ -136,6 +142,15 @@ int cfs_hip_sym_spmv_local_async(cfs_hip_sym_t h, void *y_block_dev,
                                  void *stream);
 int cfs_hip_sym_recv_fold_async(cfs_hip_sym_t h, void *y_block_dev,
                                 const void *recv_buf_dev, void *stream);
+/* The SpMV of a handle is two launches: the tile kernel (streams the matrix;
+ * the roofline kernel) and the halo fold (+ pack for shards).  This entry point
+ * enqueues only the selected ones so that bench.py can bracket each with HIP
+ * events; phases = CFS_HIP_PHASE_TILES | CFS_HIP_PHASE_FOLD is a full SpMV.   */
+#define CFS_HIP_PHASE_TILES 1
+#define CFS_HIP_PHASE_FOLD 2
+int cfs_hip_sym_spmv_phases_async(cfs_hip_sym_t h, void *y_block_dev,
+                                  const void *x_dev, void *send_buf_dev,
+                                  int phases, void *stream);
 
 /* ---- introspection (A->nnz(), A->size(), and what bench.py needs) --------- */
 typedef struct {
@@ -179,6 +194,15 @@ int cfs_hip_sym_plan_check_f32(int n, const int *rowptr, const int *colind,
                                const float *values, int nranks, int rank,
                                const int *row_splits, const cfs_hip_options *opt,
                                cfs_hip_plan_report *report);
+
+/* host-only: the send side of rank `rank`'s shard (what cfs_hip_sym_shard_send_
+ * counts / _rows would return) without touching a device; used by the CPU
+ * (gloo) tests of the exchange.  rows may be NULL to query *nrows_out.        */
+int cfs_hip_sym_plan_send_info_f64(int n, const int *rowptr, const int *colind,
+                                   const double *values, int nranks, int rank,
+                                   const int *row_splits, const cfs_hip_options *opt,
+                                   int *send_counts, int *rows, int rows_cap,
+                                   int *nrows_out);
 
 /* ---- general CSR (replaces cpu_mv / cpu_mv_serial, csr_matrix.tpp:2664-2704:
  *      Format::csr and the silent fall-back for non-symmetric files,

@@ -16,8 +16,9 @@ y = torch.empty(n, dtype=torch.float64, device="cuda")
 for cfg in configs:
     slots, block = (int(v) for v in cfg.split(",")[:2])
     mtn = int(cfg.split(",")[2]) if cfg.count(",") >= 2 else 0
+    flags = int(cfg.split(",")[3]) if cfg.count(",") >= 3 else 0
     t = time.time()
-    A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(slots, mtn, block))
+    A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(slots, mtn, block, flags))
     st = A.stats()
     tp = time.time() - t
     for _ in range(5):
@@ -30,8 +31,13 @@ for cfg in configs:
         A.dense_vector_multiply(y, x)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
+    e0.record()
+    for _ in range(iters):
+        A.spmv_phases(y, x, None, 1)
+    e1.record(); torch.cuda.synchronize()
+    ms_tile = e0.elapsed_time(e1) / iters
     alg = st["bytes_algorithmic"]
-    print(json.dumps(dict(cfg=cfg, ms=round(ms, 4), alg_GBs=round(alg / ms / 1e6, 1),
+    print(json.dumps(dict(cfg=cfg, ms=round(ms, 4), tile_ms=round(ms_tile, 4), tile_frac=round(alg / ms_tile / 1e6 / 8000, 3), alg_GBs=round(alg / ms / 1e6, 1),
                           frac=round(alg / ms / 1e6 / 8000, 3), streamed_GBs=round(st["bytes_streamed"] / ms / 1e6, 1),
                           gflops=round(2 * st["nnz_full"] / ms / 1e6, 1), tiles=st["ntiles"], halo=st["halo_slots"],
                           lds=st["lds_bytes"], preproc_s=round(tp, 2))), flush=True)
