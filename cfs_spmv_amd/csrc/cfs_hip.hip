@@ -886,6 +886,10 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
                       const cfs_hip_options *opt, cfs_hip_plan_report *rep) {
   if (!rep) return set_err(CFS_HIP_ERR_ARG, "report is NULL");
   memset(rep, 0, sizeof *rep);
+  if (n < 0 || !rowptr || (n > 0 && rowptr[n] > 0 && (!colind || !values)))
+    return set_err(CFS_HIP_ERR_ARG, "null CSR array");
+  if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !row_splits))
+    return set_err(CFS_HIP_ERR_ARG, "bad rank / nranks / row_splits");
   SymPlan<V> P;
   if (!cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
                                nranks > 1 ? row_splits : nullptr, to_opts(opt), P))
@@ -981,7 +985,9 @@ int cfs_hip_sym_plan_send_info_f64(int n, const int *rowptr, const int *colind,
                                    const int *row_splits, const cfs_hip_options *opt,
                                    int *send_counts, int *rows, int rows_cap,
                                    int *nrows_out) {
-  if (!send_counts || !nrows_out || !row_splits) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  if (!send_counts || !nrows_out || !row_splits || !rowptr || n < 0 || nranks < 1 || rank < 0 ||
+      rank >= nranks)
+    return set_err(CFS_HIP_ERR_ARG, "null / bad argument");
   SymPlan<double> P;
   if (!cfs_plan::build_plan<double>(n, rowptr, colind, values, nranks, rank, row_splits,
                                     to_opts(opt), P))

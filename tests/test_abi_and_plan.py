@@ -1,0 +1,135 @@
+"""CPU-side checks of the product library (no compute calls without a GPU):
+the C-ABI library loads and exports every symbol include/cfs_hip.h declares, and
+the host-side tile schedule (what tune() uploads) encodes exactly the input."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cfs_spmv_amd as cfs
+from cfs_spmv_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "cfs_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(cfs_hip_\w+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = cfs.load()
+    assert lib.cfs_hip_abi_version() == 1
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for name in syms:
+        assert hasattr(lib, name), f"{name} declared in cfs_hip.h but not exported"
+    assert sorted(_lib.SYMBOLS) == syms, "cfs_spmv_amd/_lib.py SYMBOLS out of date"
+    # raw dlsym as well (no ctypes caching involved)
+    raw = C.CDLL(cfs.lib_path())
+    for name in syms:
+        getattr(raw, name)
+
+
+def test_missing_extension_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "HERE", str(tmp_path))
+    with pytest.raises(_lib.CfsHipError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_bad_arguments_return_error_codes():
+    lib = cfs.load()
+    assert lib.cfs_hip_sym_destroy(None) == 0
+    rep = _lib.PlanReport()
+    rc = lib.cfs_hip_sym_plan_check_f64(4, None, None, None, 1, 0, None, None, C.byref(rep))
+    assert rc != 0
+    with pytest.raises(_lib.CfsHipError):
+        _lib.check(rc)
+    opt = cfs.make_options(block_threads=300)
+    n, rp, ci, va = synth.random_symmetric(50, 3, 1)
+    with pytest.raises(_lib.CfsHipError, match="block_threads"):
+        cfs.plan_check(n, rp, ci, va, options=opt)
+
+
+CASES = [("pdb1HYS", 0.1), ("pwtk", 0.05), ("ldoor", 0.02), ("Flan_1565", 0.02),
+         ("Queen_4147", 0.005)]
+
+
+@pytest.mark.parametrize("name,scale", CASES)
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_schedule_encodes_the_lower_triangle(name, scale, dtype):
+    n, rp, ci, va, low = synth.generate(name, scale)
+    rep = cfs.plan_check(n, rp, ci, va.astype(dtype))
+    assert rep["mismatches"] == 0
+    assert rep["decoded"] == rep["nnz_low"] == low
+    assert rep["ngroups"] % 8 == 0 and rep["ntiles"] >= 1
+    assert rep["stream_len"] <= low + 8 * rep["nslices"] + 8 * rep["ntiles"]  # no padding entries
+
+
+@pytest.mark.parametrize("slots,block", [(64, 256), (128, 512), (777, 256), (2560, 512),
+                                         (5120, 1024), (10240, 1024)])
+def test_schedule_options(slots, block):
+    n, rp, ci, va, low = synth.generate("pwtk", 0.05)
+    rep = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(slots, 0, block))
+    assert rep["mismatches"] == 0 and rep["decoded"] == low
+    assert rep["lds_slots"] <= max(64, (min(slots, 10 * block) + 63) // 64 * 64)
+
+
+@pytest.mark.parametrize("n,avg,band", [(1, 0, None), (2, 1, None), (63, 2, None), (64, 5, None),
+                                        (65, 5, None), (500, 30, 40), (3000, 4, None)])
+def test_schedule_small_and_ragged(n, avg, band):
+    n, rp, ci, va = synth.random_symmetric(n, avg, seed=n, band=band)
+    rep = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(max_slots=256))
+    assert rep["mismatches"] == 0
+
+
+def test_schedule_rows_without_diagonal_and_empty_rows():
+    import scipy.sparse as sp
+    n = 300
+    rng = np.random.default_rng(0)
+    L = sp.random(n, n, density=0.02, random_state=1, format="csr")
+    L = sp.tril(L, k=-1).tolil()
+    L[100:140, :] = 0  # rows with no lower entries
+    A = (L + L.T + sp.diags(np.where(np.arange(n) % 7 == 0, 0.0, 1.0))).tocsr()
+    A.eliminate_zeros()
+    A.sort_indices()
+    rep = cfs.plan_check(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data)
+    assert rep["mismatches"] == 0
+
+
+def test_dense_row_is_rejected_not_mangled():
+    import scipy.sparse as sp
+    n = 400
+    L = sp.lil_matrix((n, n))
+    L[n - 1, :n - 1] = 1.0  # arrow: last row touches every column
+    A = (L + L.T + sp.identity(n)).tocsr()
+    A.sort_indices()
+    with pytest.raises(_lib.CfsHipError, match="dense row"):
+        cfs.plan_check(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data,
+                       options=cfs.make_options(max_slots=128))
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_shard_schedules(nranks):
+    n, rp, ci, va, low = synth.generate("Flan_1565", 0.02)
+    rs = cfs.balanced_splits(n, rp, ci, nranks)
+    assert rs[0] == 0 and rs[-1] == n and np.all(np.diff(rs) >= 0)
+    assert all(int(v) % 16 == 0 for v in rs[1:-1])  # BlkFactor alignment, csr_matrix.tpp:418
+    tot, sent = 0, 0
+    for r in range(nranks):
+        rep = cfs.plan_check(n, rp, ci, va, nranks, r, rs)
+        assert rep["mismatches"] == 0
+        tot += rep["nnz_low"]
+        counts, rows = cfs.plan_send_info(n, rp, ci, va, nranks, r, rs)
+        assert counts.sum() == rows.size == rep["remote_vals"]
+        assert np.all(counts[r:] == 0)  # contributions only flow to LOWER ranks
+        assert np.all(rows < rs[r]) and np.all(np.diff(rows) > 0)
+        sent += rows.size
+    assert tot == low
+    # nnz balance within 10 %
+    per = [cfs.plan_check(n, rp, ci, va, nranks, r, rs)["nnz_low"] for r in range(nranks)]
+    assert max(per) <= 1.1 * (low / nranks) + 1000

@@ -1,0 +1,112 @@
+"""N > 1 path on CPU: world_size 2 and 3 over the `gloo` backend.
+
+The exchange logic (cfs_spmv_amd/dist.py: counts + row lists all-to-all, the
+per-step all-to-all of packed contributions, owner-side fold) is the code under
+test.  The per-rank device work is replaced by a host DOUBLE that lives only in
+this test (scipy arithmetic on the shard's rows) but takes its packing order --
+send_counts / send_rows -- from the real host-side schedule
+(cfs_hip_sym_plan_send_info), exactly what SymMatrix reports on a GPU box."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class HostShardDouble:
+    def __init__(self, n, rp, ci, va, nranks, rank, rs):
+        import scipy.sparse as sp
+        import cfs_spmv_amd as cfs
+        self.row_begin, self.row_end = int(rs[rank]), int(rs[rank + 1])
+        A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+        blk = A[self.row_begin:self.row_end, :]
+        self.L = sp.tril(blk, k=self.row_begin - 1).tocsr()  # strict lower of the block rows
+        self.d = A.diagonal()[self.row_begin:self.row_end]
+        self.counts, self.rows = cfs.plan_send_info(n, rp, ci, va, nranks, rank, rs)
+        self.recv_rows = None
+
+    def send_counts(self):
+        return self.counts
+
+    def send_rows(self):
+        return self.rows
+
+    def set_recv(self, rows):
+        self.recv_rows = np.asarray(rows, dtype=np.int64)
+
+    def spmv_local(self, y_block, x, send):
+        xn = x.numpy()
+        rb, re = self.row_begin, self.row_end
+        yt = self.L.T @ xn[rb:re]            # transposed updates, all columns < re
+        y = self.d * xn[rb:re] + self.L @ xn + yt[rb:re]
+        y_block.numpy()[:] = y
+        if self.rows.size:
+            send.numpy()[:self.rows.size] = yt[self.rows]
+
+    def recv_fold(self, y_block, recv):
+        if self.recv_rows is not None and self.recv_rows.size:
+            np.add.at(y_block.numpy(), self.recv_rows - self.row_begin,
+                      recv.numpy()[:self.recv_rows.size])
+
+
+def _worker(rank, world, port, name, scale, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch
+        import torch.distributed as dist
+        import cfs_spmv_amd as cfs
+        from cfs_spmv_amd import synth
+        from cfs_spmv_amd.dist import ShardedSym
+        from oracle import oracle
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n, rp, ci, va, _ = synth.generate(name, scale)
+        x = synth.make_x(n)
+        rs = cfs.balanced_splits(n, rp, ci, world)
+        be = HostShardDouble(n, rp, ci, va, world, rank, rs)
+        sh = ShardedSym(be, world, rank, np.float64, torch.device("cpu"))
+        xt = torch.from_numpy(x.copy())
+        yb = torch.full((be.row_end - be.row_begin,), 7.0, dtype=torch.float64)
+        for _ in range(2):  # twice: buffers are reused
+            sh.spmv(yb, xt)
+        y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+        sl = slice(be.row_begin, be.row_end)
+        den = np.maximum(np.abs(y_ld[sl]), absrow[sl])
+        err = float(np.max(np.abs(yb.numpy() - y_ld[sl]) / den)) if den.size else 0.0
+        # what this rank received must be exactly the rows the others aimed at it
+        ok_rows = bool(np.all((be.recv_rows >= be.row_begin) & (be.recv_rows < be.row_end))) \
+            if be.recv_rows is not None and be.recv_rows.size else True
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, err, ok_rows, int(sh.nsend), int(sh.nrecv)))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, f"{e}\n{traceback.format_exc()}", False, 0, 0))
+
+
+@pytest.mark.parametrize("world,name,scale", [(2, "Flan_1565", 0.01), (3, "pwtk", 0.03),
+                                              (2, "ldoor", 0.01)])
+def test_sharded_exchange_gloo(world, name, scale):
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, scale, q))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    res.sort()
+    for rank, err, ok_rows, nsend, nrecv in res:
+        assert not isinstance(err, str), f"rank {rank} failed: {err}"
+        assert err <= 1e-12 and ok_rows, (rank, err)
+    assert sum(r[3] for r in res) == sum(r[4] for r in res) > 0  # every packed value arrives
+    assert res[0][3] == 0  # rank 0 owns the first rows: nothing to send

@@ -146,3 +146,53 @@ def test_csr_general_parity():
             y_ld, absrow = oracle.csr_spmv_ld(m, rp, ci, va, np.resize(x, k))
             assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
             G.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_shards_on_one_device(nranks, dtype):
+    """1-D row-block shards, all on cuda:0: local tile kernels, pack of
+    the off-block contributions, routing by the static row lists (what the RCCL
+    all-to-all does between processes), owner-side fold"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from oracle import oracle
+    torch = _torch()
+    n, rp, ci, va, _ = synth.generate("Flan_1565", 0.02)
+    va = va.astype(dtype)
+    x = synth.make_x(n, 42, dtype)
+    rs = cfs.balanced_splits(n, rp, ci, nranks)
+    xd = torch.from_numpy(x).cuda()
+    tdt = xd.dtype
+    shards = [cfs.SymMatrix(n, rp, ci, va, row_splits=rs, rank=r) for r in range(nranks)]
+    send_rows = [s.send_rows() for s in shards]
+    send_counts = [s.send_counts() for s in shards]
+    # receive lists: concatenation by source rank of the rows aimed at me
+    recv_rows = []
+    for r in range(nranks):
+        parts = []
+        for src in range(nranks):
+            off = int(send_counts[src][:r].sum())
+            parts.append(send_rows[src][off:off + int(send_counts[src][r])])
+        recv_rows.append(np.concatenate(parts) if parts else np.zeros(0, np.int32))
+        shards[r].set_recv(recv_rows[r])
+    y = np.zeros(n, dtype=dtype)
+    send_bufs, yb = [], []
+    for r, s in enumerate(shards):
+        yb.append(torch.full((int(rs[r + 1] - rs[r]),), 3.0, dtype=tdt, device="cuda"))
+        send_bufs.append(torch.zeros(max(1, send_rows[r].size), dtype=tdt, device="cuda"))
+        s.spmv_local(yb[r], xd, send_bufs[r])
+    torch.cuda.synchronize()
+    for r, s in enumerate(shards):
+        parts = []
+        for src in range(nranks):
+            off = int(send_counts[src][:r].sum())
+            parts.append(send_bufs[src][off:off + int(send_counts[src][r])])
+        recv = torch.cat(parts) if recv_rows[r].size else torch.zeros(1, dtype=tdt, device="cuda")
+        s.recv_fold(yb[r], recv)
+        torch.cuda.synchronize()
+        y[rs[r]:rs[r + 1]] = yb[r].cpu().numpy()
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
+    for s in shards:
+        s.close()
