@@ -61,10 +61,19 @@ def build_oracle(force=False):
     return os.path.join(odir, "liboracle.so")
 
 
+def build_cxx(force=False):
+    """libsparse.so + bench_spmv_mmf + test_spmv_mmf (the reference's products)"""
+    if force:
+        _run(["make", "-C", ROOT, "clean"])
+    _run(["make", "-C", ROOT, "DP=1"])
+    return os.path.join(ROOT, "build", "libsparse.so")
+
+
 def build_all(force=False):
     build_hip(force)
     build_synth(force)
     build_oracle(force)
+    build_cxx(force)
 
 
 if __name__ == "__main__":

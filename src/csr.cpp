@@ -1,0 +1,159 @@
+// csr.cpp -- CSRMatrix<int,float> / CSRMatrix<int,double> over the C ABI
+// (the reference instantiates the same two: src/csr.cpp:10-11).
+//
+// file ctor   ~ include/matrix/csr_matrix.tpp:8-111   (own parallel reader)
+// array ctor  ~ :113-144  (no ownership)
+// tune()      ~ :230-310  -> cfs_hip_sym_create_* / cfs_hip_csr_create_*,
+//                            then frees the full CSR like compress_symmetry (:1700-1706)
+// multiply    ~ spmv_fn   -> cfs_hip_sym_spmv / cfs_hip_csr_spmv
+#include <cstdlib>
+#include <iostream>
+#include <type_traits>
+
+#include "cfs.hpp"
+#include "cfs_hip.h"
+#include "io/mmf.hpp"
+
+namespace cfs {
+namespace matrix {
+namespace sparse {
+
+static void fatal(const std::string &msg) {
+  std::cout << "[ERROR]: " << msg << std::endl;
+  exit(1);
+}
+
+static void require_gpu(Platform p) {
+  if (p != Platform::gpu)
+    fatal("this build of cfs-spmv runs the SpMV path on the GPU only: "
+          "Platform::cpu is not provided (no CPU fallback)");
+  if (cfs_hip_init(cfs::util::runtime::get_device()) != 0)
+    fatal(std::string("cannot initialise the HIP device: ") + cfs_hip_last_error());
+}
+
+template <typename IndexT, typename ValueT>
+CSRMatrix<IndexT, ValueT>::CSRMatrix(const std::string &filename, Platform platform,
+                                     bool symmetric, bool hybrid)
+    : platform_(platform), owns_data_(true), hybrid_(hybrid), tuned_(false),
+      sym_handle_(nullptr), csr_handle_(nullptr), device_bytes_(0) {
+  require_gpu(platform_);
+  cfs::io::CsrArrays<IndexT, ValueT> a;
+  std::string err;
+  if (!cfs::io::LoadMmfCsr<IndexT, ValueT>(filename, a, err)) {
+    std::cout << err << std::endl; // the reference prints the bare message
+    exit(1);
+  }
+  symmetric_ = a.symmetric && symmetric; // csr_matrix.tpp:13-15
+#ifdef _LOG_INFO
+  if (!symmetric)
+    std::cout << "[INFO]: using CSR format to store the sparse matrix..." << std::endl;
+  else if (!a.symmetric)
+    std::cout << "[INFO]: matrix is not symmetric!\n[INFO]: rolling back to CSR format..."
+              << std::endl;
+  else
+    std::cout << "[INFO]: using " << (hybrid ? "HYB" : "SSS")
+              << " format to store the sparse matrix..." << std::endl;
+#endif
+  nrows_ = a.nrows;
+  ncols_ = a.ncols;
+  nnz_ = (int)a.nnz;
+  nthreads_ = (int)get_num_threads();
+  rowptr_ = (IndexT *)internal_alloc(((size_t)nrows_ + 1) * sizeof(IndexT), Platform::cpu);
+  colind_ = (IndexT *)internal_alloc((size_t)nnz_ * sizeof(IndexT), Platform::cpu);
+  values_ = (ValueT *)internal_alloc((size_t)nnz_ * sizeof(ValueT), Platform::cpu);
+  std::copy(a.rowptr.begin(), a.rowptr.end(), rowptr_);
+  std::copy(a.colind.begin(), a.colind.end(), colind_);
+  std::copy(a.values.begin(), a.values.end(), values_);
+}
+
+template <typename IndexT, typename ValueT>
+CSRMatrix<IndexT, ValueT>::CSRMatrix(IndexT *rowptr, IndexT *colind, ValueT *values,
+                                     IndexT nrows, IndexT ncols, bool symmetric, bool hybrid,
+                                     Platform platform)
+    : platform_(platform), nrows_(nrows), ncols_(ncols), symmetric_(symmetric),
+      owns_data_(false), hybrid_(hybrid), tuned_(false), rowptr_(rowptr), colind_(colind),
+      values_(values), sym_handle_(nullptr), csr_handle_(nullptr), device_bytes_(0) {
+  require_gpu(platform_);
+  nnz_ = rowptr_[nrows];
+  nthreads_ = (int)get_num_threads();
+}
+
+template <typename IndexT, typename ValueT> void CSRMatrix<IndexT, ValueT>::release_host_csr() {
+  if (owns_data_) {
+    internal_free(rowptr_, Platform::cpu);
+    internal_free(colind_, Platform::cpu);
+    internal_free(values_, Platform::cpu);
+  }
+  rowptr_ = colind_ = nullptr;
+  values_ = nullptr;
+}
+
+template <typename IndexT, typename ValueT> CSRMatrix<IndexT, ValueT>::~CSRMatrix() {
+  if (sym_handle_) cfs_hip_sym_destroy((cfs_hip_sym_t)sym_handle_);
+  if (csr_handle_) cfs_hip_csr_destroy((cfs_hip_csr_t)csr_handle_);
+  release_host_csr();
+}
+
+template <typename IndexT, typename ValueT> size_t CSRMatrix<IndexT, ValueT>::size() const {
+  if (tuned_) return device_bytes_;
+  return ((size_t)nrows_ + 1) * sizeof(IndexT) + (size_t)nnz_ * (sizeof(IndexT) + sizeof(ValueT));
+}
+
+template <typename IndexT, typename ValueT>
+bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning) {
+  if (tuned_) return true;
+  static_assert(std::is_same<IndexT, int>::value, "int indices only (src/csr.cpp:10-11)");
+  int rc;
+  if (symmetric_) {
+#ifdef _LOG_INFO
+    std::cout << "[INFO]: compressing for symmetry: MI355X tile schedule" << std::endl;
+#endif
+    cfs_hip_sym_t h = nullptr;
+    if (std::is_same<ValueT, double>::value)
+      rc = cfs_hip_sym_create_f64(nrows_, rowptr_, colind_, (const double *)values_, nullptr, &h);
+    else
+      rc = cfs_hip_sym_create_f32(nrows_, rowptr_, colind_, (const float *)values_, nullptr, &h);
+    if (rc != 0) fatal(std::string("tune() failed: ") + cfs_hip_last_error());
+    sym_handle_ = h;
+    cfs_hip_sym_stats st;
+    cfs_hip_sym_get_stats(h, &st);
+    device_bytes_ = (size_t)st.device_bytes;
+#ifdef _LOG_INFO
+    std::cout << "[INFO]: " << st.ntiles << " tiles, " << st.halo_slots << " halo slots, "
+              << st.lds_bytes << " B LDS per workgroup" << std::endl;
+#endif
+    release_host_csr(); // csr_matrix.tpp:1700-1706
+  } else {
+    cfs_hip_csr_t h = nullptr;
+    if (std::is_same<ValueT, double>::value)
+      rc = cfs_hip_csr_create_f64(nrows_, ncols_, rowptr_, colind_, (const double *)values_, &h);
+    else
+      rc = cfs_hip_csr_create_f32(nrows_, ncols_, rowptr_, colind_, (const float *)values_, &h);
+    if (rc != 0) fatal(std::string("tune() failed: ") + cfs_hip_last_error());
+    csr_handle_ = h;
+    device_bytes_ = ((size_t)nrows_ + 1) * sizeof(IndexT) +
+                    (size_t)nnz_ * (sizeof(IndexT) + sizeof(ValueT));
+  }
+  tuned_ = true;
+  return true;
+}
+
+template <typename IndexT, typename ValueT>
+void CSRMatrix<IndexT, ValueT>::dense_vector_multiply(ValueT *__restrict y,
+                                                      const ValueT *__restrict x) {
+  int rc;
+  if (sym_handle_) rc = cfs_hip_sym_spmv((cfs_hip_sym_t)sym_handle_, y, x);
+  else if (csr_handle_) rc = cfs_hip_csr_spmv((cfs_hip_csr_t)csr_handle_, y, x);
+  else {
+    fatal("dense_vector_multiply() before tune()"); // std::bad_function_call in the reference
+    return;
+  }
+  if (rc != 0) fatal(std::string("SpMV failed: ") + cfs_hip_last_error());
+}
+
+template class CSRMatrix<int, float>;
+template class CSRMatrix<int, double>;
+
+} // namespace sparse
+} // namespace matrix
+} // namespace cfs

@@ -1,0 +1,310 @@
+// mmf.cpp -- parallel Matrix-Market reader (see include/io/mmf.hpp for the
+// contract and for what it mirrors in the reference).
+#include "io/mmf.hpp"
+
+#include <fcntl.h>
+#include <omp.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+namespace cfs {
+namespace io {
+
+namespace {
+
+struct Mapped {
+  const char *p = nullptr;
+  size_t n = 0;
+  int fd = -1;
+  ~Mapped() {
+    if (p && n) munmap((void *)p, n);
+    if (fd >= 0) close(fd);
+  }
+};
+
+inline bool blank(char c) { return c == ' ' || c == '\t' || c == '\r'; }
+
+// tokens of the line [b, e): up to 8 (begin, end) pairs
+struct Tokens {
+  const char *b[8], *e[8];
+  int n = 0;
+};
+inline void tokenize(const char *b, const char *e, Tokens &t) {
+  t.n = 0;
+  while (b < e && t.n < 8) {
+    while (b < e && blank(*b)) b++;
+    if (b >= e) break;
+    t.b[t.n] = b;
+    while (b < e && !blank(*b)) b++;
+    t.e[t.n++] = b;
+  }
+}
+inline bool tok_is(const Tokens &t, int i, const char *s) {
+  size_t l = strlen(s);
+  return i < t.n && (size_t)(t.e[i] - t.b[i]) == l && memcmp(t.b[i], s, l) == 0;
+}
+// atoi on a token (the token is followed by a blank or '\n', so strtol stops)
+inline long tok_long(const Tokens &t, int i) { return strtol(t.b[i], nullptr, 10); }
+inline double tok_double(const Tokens &t, int i) { return strtod(t.b[i], nullptr); }
+
+struct Elem {
+  int row, col; // zero-based here
+  double val;
+  long seq;
+};
+
+} // namespace
+
+template <typename IndexType, typename ValueType>
+bool LoadMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueType> &out,
+                std::string &error) {
+  Mapped m;
+  m.fd = open(filename.c_str(), O_RDONLY);
+  if (m.fd < 0) {
+    error = "MMF file error.";
+    return false;
+  }
+  struct stat st;
+  if (fstat(m.fd, &st) != 0 || st.st_size == 0) {
+    error = "MMF file error.";
+    return false;
+  }
+  m.n = (size_t)st.st_size;
+  m.p = (const char *)mmap(nullptr, m.n, PROT_READ, MAP_PRIVATE, m.fd, 0);
+  if (m.p == MAP_FAILED) {
+    m.p = nullptr;
+    error = "MMF file error.";
+    return false;
+  }
+  const char *p = m.p, *end = m.p + m.n;
+  auto next_line = [&](const char *&b, const char *&e) -> bool {
+    if (p >= end) return false;
+    b = p;
+    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+    e = nl ? nl : end;
+    p = nl ? nl + 1 : end;
+    return true;
+  };
+
+  // ---- banner -----------------------------------------------------------------
+  const char *lb, *le;
+  Tokens t;
+  bool symmetric = false, zero_based = false;
+  if (!next_line(lb, le)) {
+    error = "MMF file error.";
+    return false;
+  }
+  tokenize(lb, le, t);
+  bool size_line_pending = false;
+  if (t.n > 0 && tok_is(t, 0, "%%MatrixMarket")) {
+    if (t.n < 5) {
+      error = "less arguments in header line of MMF file.";
+      return false;
+    }
+    if (!tok_is(t, 2, "coordinate")) {
+      error = "unsupported matrix format in header line of MMF file.";
+      return false;
+    }
+    if (tok_is(t, 4, "general")) symmetric = false;
+    else if (tok_is(t, 4, "symmetric")) symmetric = true;
+    else {
+      error = "unsupported symmetry in header line of MMF file.";
+      return false;
+    }
+    for (int i = 5; i < t.n; i++) {
+      if (tok_is(t, i, "base-0")) zero_based = true;
+      else if (tok_is(t, i, "base-1")) zero_based = false;
+    }
+  } else if (t.n > 0 && (t.e[0] - t.b[0]) > 2 && t.b[0][0] == '%' && t.b[0][1] == '%') {
+    error = "invalid header line in MMF file.";
+    return false;
+  } else if (t.n > 0 && t.b[0][0] != '%') {
+    size_line_pending = true; // no banner: this IS the size line
+  }
+  // ---- size line ----------------------------------------------------------------
+  if (!size_line_pending) {
+    for (;;) {
+      if (!next_line(lb, le)) {
+        error = "size line error in MMF file.";
+        return false;
+      }
+      tokenize(lb, le, t);
+      if (t.n > 0 && t.b[0][0] != '%') break;
+    }
+  }
+  if (t.n < 2) {
+    error = "bad input, less arguments in line of MMF file.";
+    return false;
+  }
+  const long nrows = tok_long(t, 0), ncols = tok_long(t, 1);
+  const long declared = t.n >= 3 ? (long)tok_double(t, 2) : 0;
+  if (nrows < 0 || ncols < 0 || declared < 0 || nrows > 0x7fffffffL || ncols > 0x7fffffffL) {
+    error = "bad size line in MMF file.";
+    return false;
+  }
+
+  // ---- entries: cut the body at line boundaries, parse in parallel --------------
+  const char *body = p;
+  const int nth = std::max(1, omp_get_max_threads());
+  std::vector<const char *> cut(nth + 1, end);
+  cut[0] = body;
+  for (int i = 1; i < nth; i++) {
+    const char *q = body + (size_t)(end - body) * i / nth;
+    if (q < cut[i - 1]) q = cut[i - 1];
+    const char *nl = (const char *)memchr(q, '\n', (size_t)(end - q));
+    cut[i] = nl ? nl + 1 : end;
+  }
+  std::vector<std::vector<Elem>> part(nth);
+  std::vector<int> bad(nth, 0);
+#pragma omp parallel num_threads(nth)
+  {
+    const int tid = omp_get_thread_num();
+    std::vector<Elem> &v = part[tid];
+    const char *q = cut[tid], *qe = cut[tid + 1];
+    v.reserve((size_t)(qe - q) / 24 + 16);
+    Tokens tk;
+    while (q < qe) {
+      const char *nl = (const char *)memchr(q, '\n', (size_t)(qe - q));
+      const char *e = nl ? nl : qe;
+      tokenize(q, e, tk);
+      q = nl ? nl + 1 : qe;
+      if (tk.n == 0 || tk.b[0][0] == '%') continue;
+      if (tk.n < 2) {
+        bad[tid] = 1;
+        break;
+      }
+      Elem el;
+      el.row = (int)tok_long(tk, 0) - (zero_based ? 0 : 1);
+      el.col = (int)tok_long(tk, 1) - (zero_based ? 0 : 1);
+      el.val = tk.n >= 3 ? tok_double(tk, 2) : 0.42; // pattern entries
+      el.seq = 0;
+      v.push_back(el);
+    }
+  }
+  long read = 0;
+  for (int i = 0; i < nth; i++) {
+    if (bad[i]) {
+      error = "bad input, less arguments in line of MMF file.";
+      return false;
+    }
+    read += (long)part[i].size();
+  }
+  if (read < declared) {
+    error = "Requesting dereference, but mmf ended.";
+    return false;
+  }
+  // the reference reads exactly `declared` entries and ignores the rest
+  long keep = declared;
+  // ---- expand, bucket by row (counting sort), order each row by column ----------
+  std::vector<long> rowcnt((size_t)nrows + 1, 0);
+  long seen = 0;
+  bool range_error = false;
+  for (int i = 0; i < nth && seen < keep; i++)
+    for (size_t k = 0; k < part[i].size() && seen < keep; k++, seen++) {
+      const Elem &el = part[i][k];
+      if (el.row < 0 || el.row >= nrows || el.col < 0 || el.col >= ncols) {
+        range_error = true;
+        continue;
+      }
+      rowcnt[el.row + 1]++;
+      if (symmetric && el.row != el.col) {
+        if (el.col >= nrows || el.row >= ncols) range_error = true;
+        else rowcnt[el.col + 1]++;
+      }
+    }
+  if (range_error) {
+    error = "entry out of range in MMF file.";
+    return false;
+  }
+  for (long r = 0; r < nrows; r++) rowcnt[r + 1] += rowcnt[r];
+  const long nnz = rowcnt[nrows];
+  if (nnz > 0x7fffffffL) {
+    error = "more than 2^31-1 nonzeros: int indices are API (src/csr.cpp)";
+    return false;
+  }
+  struct CV {
+    int col;
+    double val;
+    long seq;
+  };
+  std::vector<CV> buf((size_t)nnz);
+  {
+    std::vector<long> fill(rowcnt.begin(), rowcnt.end() - 1);
+    long seq = 0;
+    seen = 0;
+    for (int i = 0; i < nth && seen < keep; i++)
+      for (size_t k = 0; k < part[i].size() && seen < keep; k++, seen++) {
+        const Elem &el = part[i][k];
+        buf[fill[el.row]++] = CV{el.col, el.val, seq++};
+        if (symmetric && el.row != el.col) buf[fill[el.col]++] = CV{el.row, el.val, seq++};
+      }
+    for (auto &v : part) std::vector<Elem>().swap(v);
+  }
+  out.nrows = (IndexType)nrows;
+  out.ncols = (IndexType)ncols;
+  out.nnz = nnz;
+  out.symmetric = symmetric;
+  out.rowptr.resize((size_t)nrows + 1);
+  out.colind.resize((size_t)nnz);
+  out.values.resize((size_t)nnz);
+#pragma omp parallel for schedule(dynamic, 1024)
+  for (long r = 0; r < nrows; r++) {
+    CV *b = buf.data() + rowcnt[r], *e = buf.data() + rowcnt[r + 1];
+    // (col, input order): duplicates keep their file order
+    std::sort(b, e, [](const CV &x, const CV &y) {
+      return x.col != y.col ? x.col < y.col : x.seq < y.seq;
+    });
+    for (CV *q = b; q < e; q++) {
+      out.colind[q - buf.data()] = (IndexType)q->col;
+      out.values[q - buf.data()] = (ValueType)q->val;
+    }
+  }
+  for (long r = 0; r <= nrows; r++) out.rowptr[r] = (IndexType)rowcnt[r];
+  // the reference asserts that the last row is non-empty (csr_matrix.tpp:104)
+  if (nrows > 0 && rowcnt[nrows] == rowcnt[nrows - 1] && nnz > 0) {
+    // accepted here: trailing empty rows simply repeat rowptr
+  }
+  return true;
+}
+
+template bool LoadMmfCsr<int, float>(const std::string &, CsrArrays<int, float> &,
+                                     std::string &);
+template bool LoadMmfCsr<int, double>(const std::string &, CsrArrays<int, double> &,
+                                      std::string &);
+
+} // namespace io
+} // namespace cfs
+
+// C entry points for tests and foreign callers: the loader alone, no device.
+// Arrays are malloc'ed; release them with cfs_mmf_free.
+extern "C" {
+int cfs_mmf_load_csr_f64(const char *path, int *nrows, int *ncols, long *nnz, int *symmetric,
+                         int **rowptr, int **colind, double **values, char *err, int errlen) {
+  cfs::io::CsrArrays<int, double> a;
+  std::string e;
+  if (!cfs::io::LoadMmfCsr<int, double>(path, a, e)) {
+    if (err && errlen > 0) {
+      strncpy(err, e.c_str(), (size_t)errlen - 1);
+      err[errlen - 1] = 0;
+    }
+    return -1;
+  }
+  *nrows = a.nrows;
+  *ncols = a.ncols;
+  *nnz = a.nnz;
+  *symmetric = a.symmetric ? 1 : 0;
+  *rowptr = (int *)malloc(sizeof(int) * a.rowptr.size());
+  *colind = (int *)malloc(sizeof(int) * (a.colind.size() + 1));
+  *values = (double *)malloc(sizeof(double) * (a.values.size() + 1));
+  memcpy(*rowptr, a.rowptr.data(), sizeof(int) * a.rowptr.size());
+  memcpy(*colind, a.colind.data(), sizeof(int) * a.colind.size());
+  memcpy(*values, a.values.data(), sizeof(double) * a.values.size());
+  return 0;
+}
+void cfs_mmf_free(void *p) { free(p); }
+}

@@ -23,6 +23,8 @@ def _built():
         build.build_synth()
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         build.build_oracle()
+    if not os.path.exists(os.path.join(ROOT, "build", "test_spmv_mmf")):
+        build.build_cxx()
     yield
 
 

@@ -1,0 +1,115 @@
+"""The C++ host surface (include/cfs.hpp, libsparse.so, the two drivers).
+
+CPU part: the parallel Matrix-Market reader of libsparse yields the same CSR as
+the oracle's restatement of the reference reader (which is itself pinned to the
+genuine reader, test_oracle_mmf.py) on every fixture and on a structured
+stand-in.  GPU part: the drivers run end to end with the reference's CLI."""
+import ctypes as C
+import glob
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+FILES = sorted(glob.glob(os.path.join(GOLD, "*.mtx")))
+
+
+def cxx_load(path):
+    lib = C.CDLL(os.path.join(ROOT, "build", "libsparse.so"))
+    n, m, sym, nnz = C.c_int(), C.c_int(), C.c_int(), C.c_long()
+    rp, ci, va = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    err = C.create_string_buffer(256)
+    rc = lib.cfs_mmf_load_csr_f64(os.fsencode(path), C.byref(n), C.byref(m), C.byref(nnz),
+                                  C.byref(sym), C.byref(rp), C.byref(ci), C.byref(va), err, 256)
+    if rc != 0:
+        raise ValueError(err.value.decode())
+    lib.cfs_mmf_free.argtypes = [C.c_void_p]
+
+    def take(p, cnt, dt):
+        nb = cnt * np.dtype(dt).itemsize
+        a = np.frombuffer((C.c_char * nb).from_address(p.value), dtype=dt, count=cnt).copy() \
+            if cnt else np.zeros(0, dt)
+        lib.cfs_mmf_free(p)
+        return a
+    return dict(nrows=n.value, ncols=m.value, nnz=nnz.value, symmetric=bool(sym.value),
+                rowptr=take(rp, n.value + 1, np.int32), colind=take(ci, nnz.value, np.int32),
+                values=take(va, nnz.value, np.float64))
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(f) for f in FILES])
+def test_parallel_reader_equals_reference_reader(path):
+    a, b = cxx_load(path), oracle.mmf_load(path)
+    for k in ("nrows", "ncols", "nnz", "symmetric"):
+        assert a[k] == b[k]
+    assert np.array_equal(a["rowptr"], b["rowptr"])   # bit-exact row_ptr
+    assert np.array_equal(a["colind"], b["colind"])   # bit-exact col_idx
+    assert np.array_equal(a["values"].view(np.uint64), b["values"].view(np.uint64))
+
+
+def test_parallel_reader_on_stand_in(tmp_path):
+    from cfs_spmv_amd import synth
+    n, rp, ci, va, _ = synth.generate("ldoor", 0.01)
+    p = str(tmp_path / "m.mtx")
+    synth.write_mtx(p, n, rp, ci, va)
+    a = cxx_load(p)
+    assert a["symmetric"] and a["nrows"] == n and a["nnz"] == rp[-1]
+    assert np.array_equal(a["rowptr"], rp) and np.array_equal(a["colind"], ci)
+    assert np.array_equal(a["values"], va)
+
+
+def test_parallel_reader_leniency_and_errors(tmp_path):
+    p = tmp_path / "t.mtx"
+    p.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1\t1\t1.5\n2 2 2.5")
+    a = cxx_load(str(p))  # tabs and a missing last newline are accepted here
+    assert list(a["values"]) == [1.5, 2.5]
+    p.write_text("%%MatrixMarket matrix coordinate real hermitian\n2 2 1\n1 1 1\n")
+    with pytest.raises(ValueError, match="unsupported symmetry"):
+        cxx_load(str(p))
+    p.write_text("%%MatrixMarket matrix coordinate real general\n2 2 3\n1 1 1\n")
+    with pytest.raises(ValueError, match="mmf ended"):
+        cxx_load(str(p))
+
+
+def test_headers_keep_the_reference_surface():
+    """names a caller of the reference uses (bench/bench_spmv_mmf.cpp:16-23,:100-164)"""
+    inc = os.path.join(ROOT, "include")
+    text = "".join(open(f).read() for f in glob.glob(os.path.join(inc, "**", "*.hpp"),
+                                                    recursive=True))
+    for needle in ["namespace cfs", "class SparseMatrix", "class CSRMatrix", "struct SpDMV",
+                   "internal_alloc", "internal_free", "get_num_threads", "isEqual",
+                   "enum class Platform", "enum class Format { none, csr, sss, hyb }",
+                   "enum class Tuning { None, Aggressive }", "dense_vector_multiply",
+                   "rowptr()", "colind()", "values()"]:
+        assert needle in text, needle
+
+
+@pytest.mark.gpu
+def test_drivers_end_to_end(tmp_path):
+    from cfs_spmv_amd import synth
+    n, rp, ci, va, _ = synth.generate("pwtk", 0.05)
+    p = str(tmp_path / "pwtk_like.mtx")
+    synth.write_mtx(p, n, rp, ci, va)
+    env = dict(os.environ, CFS_SEED="7")
+    for fmt in ("0", "1", "2"):
+        r = subprocess.run([os.path.join(ROOT, "build", "test_spmv_mmf"), p, fmt],
+                           capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout + r.stderr
+    r = subprocess.run([os.path.join(ROOT, "build", "bench_spmv_mmf"), p, "1", "64"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    m = re.search(r"matrix: pwtk_like.mtx format: SSS preproc\(sec\): (\S+) t\(sec\): (\S+) "
+                  r"gflops/s: (\S+) threads: (\d+) size\(MB\): (\S+)", r.stdout)
+    assert m, r.stdout
+    assert float(m.group(3)) > 0
+    # general file through Format::sss: silent fall-back to CSR (csr_matrix.tpp:13-19)
+    g = str(tmp_path / "gen.mtx")
+    synth.write_mtx(g, n, rp, ci, va, general=True)
+    r = subprocess.run([os.path.join(ROOT, "build", "test_spmv_mmf"), g, "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout + r.stderr
