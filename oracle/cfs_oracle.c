@@ -400,19 +400,60 @@ typedef struct {
   int V;
 } graph_t;
 
+/* per-thread edge SET (the reference inserts into tbb concurrent sets, so an
+ * edge found a million times is stored once; a plain list would need
+ * O(rows * deg^2) memory at high thread counts): open addressing on the
+ * packed undirected pair (min << 32 | max).                                  */
 typedef struct {
-  long *e; /* packed (u << 32 | v) directed pairs */
+  unsigned long *slot; /* 0 = empty (pair (0,0) is a self loop, never stored) */
   long n, cap;
+  long *e; /* filled by eb_finish: both directions, packed (u << 32 | v) */
 } edgebuf_t;
+
+static void eb_insert_raw(edgebuf_t *b, unsigned long key) {
+  unsigned long h = key * 0x9e3779b97f4a7c15UL;
+  long i = (long)(h >> 20) & (b->cap - 1);
+  while (b->slot[i] != 0) {
+    if (b->slot[i] == key) return;
+    i = (i + 1) & (b->cap - 1);
+  }
+  b->slot[i] = key;
+  b->n++;
+}
 
 static void eb_push(edgebuf_t *b, int u, int v) {
   if (u == v) return; /* cannot happen, see graph_from_edges */
-  if (b->n + 2 > b->cap) {
-    b->cap = b->cap ? b->cap * 2 : 1024;
-    b->e = (long *)realloc(b->e, sizeof(long) * (size_t)b->cap);
+  if (b->cap == 0) {
+    b->cap = 1024;
+    b->slot = (unsigned long *)calloc((size_t)b->cap, sizeof(unsigned long));
+  } else if (2 * (b->n + 1) > b->cap) {
+    edgebuf_t nb = {0};
+    nb.cap = b->cap * 2;
+    nb.slot = (unsigned long *)calloc((size_t)nb.cap, sizeof(unsigned long));
+    for (long i = 0; i < b->cap; i++)
+      if (b->slot[i]) eb_insert_raw(&nb, b->slot[i]);
+    free(b->slot);
+    b->slot = nb.slot;
+    b->cap = nb.cap;
+    b->n = nb.n;
   }
-  b->e[b->n++] = ((long)u << 32) | (unsigned int)v;
-  b->e[b->n++] = ((long)v << 32) | (unsigned int)u;
+  unsigned long lo = (unsigned long)(u < v ? u : v), hi = (unsigned long)(u < v ? v : u);
+  eb_insert_raw(b, (lo << 32) | hi);
+}
+
+/* expand the set into the directed pair list graph_from_edges consumes */
+static void eb_finish(edgebuf_t *b) {
+  long m = 0;
+  b->e = (long *)malloc(sizeof(long) * (size_t)(2 * b->n + 1));
+  for (long i = 0; i < b->cap; i++)
+    if (b->slot[i]) {
+      unsigned long lo = b->slot[i] >> 32, hi = b->slot[i] & 0xffffffffUL;
+      b->e[m++] = (long)((lo << 32) | hi);
+      b->e[m++] = (long)((hi << 32) | lo);
+    }
+  free(b->slot);
+  b->slot = NULL;
+  b->n = m;
 }
 
 static int long_cmp(const void *a, const void *b) {
