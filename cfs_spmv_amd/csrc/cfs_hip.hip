@@ -95,17 +95,23 @@ __device__ __forceinline__ void fetch_packet(Pkt<float> &p, const float *tv,
 
 // one stored nonzero a = A[row][col(c)]: row side into the register
 // accumulator, transposed side into the LDS y window (ds_add_f64 / ds_add_f32)
+//
+// The y window is ALWAYS fp64: on gfx950 ds_add_f64 runs at the rate of the
+// matrix stream while ds_add_f32 is ~4x slower under this access pattern
+// (measured: fp32 tile kernel 0.370 ms with ds_add_f32 vs 0.084 ms without the
+// transposed atomics), so the single-precision build accumulates the window in
+// double and rounds once when the window is flushed.
 template <typename V, int MODE>
-__device__ __forceinline__ void lds_update(const V *xl, V *yl, V a, unsigned c, V xi, V &acc) {
+__device__ __forceinline__ void lds_update(const V *xl, double *yl, V a, unsigned c, V xi, V &acc) {
   if (MODE == 2) {
     acc = fma(a, xi + V(c), acc);
   } else {
     acc = fma(a, xl[c], acc);
-    if (MODE == 0) atomicAdd(&yl[c], a * xi);
+    if (MODE == 0) atomicAdd(&yl[c], (double)a * (double)xi);
   }
 }
 template <typename V, int MODE>
-__device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, V *yl, V xi, V &acc) {
+__device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, double *yl, V xi, V &acc) {
   lds_update<V, MODE>(xl, yl, p.v[0], p.c.x, xi, acc);
   lds_update<V, MODE>(xl, yl, p.v[1], p.c.y, xi, acc);
   lds_update<V, MODE>(xl, yl, p.v[2], p.c.z, xi, acc);
@@ -113,10 +119,10 @@ __device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, V *
 }
 // one COO leftover a = A[row(r)][col(c)]: both sides through LDS atomics
 template <typename V, int MODE>
-__device__ __forceinline__ void coo_update(const V *xl, V *yl, V a, unsigned r, unsigned c) {
+__device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigned r, unsigned c) {
   if (MODE == 0 || MODE == 1) {
-    atomicAdd(&yl[r], a * xl[c]);
-    if (MODE == 0) atomicAdd(&yl[c], a * xl[r]);
+    atomicAdd(&yl[r], (double)a * (double)xl[c]);
+    if (MODE == 0) atomicAdd(&yl[c], (double)a * (double)xl[r]);
   }
 }
 
@@ -169,8 +175,8 @@ __global__ void __launch_bounds__(BLOCK)
   } d = {a_tiles, a_group_ptr, a_halo_col, a_rowinfo, a_diag, a_slice_meta, a_vals,
          a_slots, a_cvals, a_crows, a_ccols, a_strip, a_row_begin, a_lds_slots};
   extern __shared__ __align__(16) unsigned char cfs_smem[];
-  V *xl = reinterpret_cast<V *>(cfs_smem);
-  V *yl = xl + d.lds_slots;
+  double *yl = reinterpret_cast<double *>(cfs_smem); // fp64 first: keeps 8-B alignment
+  V *xl = reinterpret_cast<V *>(yl + d.lds_slots);
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform by construction: keep it in an SGPR so that slice bookkeeping is
   // scalar (s_load / s_cbranch) and never waits on the vector-memory counter
@@ -262,12 +268,12 @@ __global__ void __launch_bounds__(BLOCK)
     for (int k = 0; k < U; ++k) {
       const int i = tid + k * BLOCK;
       if (MODE != 4) {
-        if (i < prev_nown) y[prev_lrow0 + i] = yl[i];
-        else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = yl[i];
+        if (i < prev_nown) y[prev_lrow0 + i] = (V)yl[i];
+        else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = (V)yl[i];
       }
       if (i < nslots) {
         xl[i] = xr[k];
-        yl[i] = V(0);
+        yl[i] = 0.0;
       }
     }
     __syncthreads();
@@ -319,7 +325,7 @@ __global__ void __launch_bounds__(BLOCK)
       } else if (amax - g == 1) {
         if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
       }
-      if (s * 64 + lane < nown) atomicAdd(&yl[r], fma(dg, xi, acc));
+      if (s * 64 + lane < nown) atomicAdd(&yl[r], (double)fma(dg, xi, acc));
     }
     // COO leftovers: packet p = wave, wave + NW, ...; the first one was requested
     // at the top of the tile
@@ -348,8 +354,8 @@ __global__ void __launch_bounds__(BLOCK)
   for (int k = 0; k < U; ++k) {
     const int i = tid + k * BLOCK;
     if (MODE == 4) break;
-    if (i < prev_nown) y[prev_lrow0 + i] = yl[i];
-    else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = yl[i];
+    if (i < prev_nown) y[prev_lrow0 + i] = (V)yl[i];
+    else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = (V)yl[i];
   }
 }
 
@@ -491,7 +497,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     dev.strip = (V *)strip.p;
     dev.row_begin = P.row_begin;
     dev.lds_slots = P.lds_slots;
-    lds_bytes = (size_t)P.lds_slots * 2 * sizeof(V);
+    lds_bytes = (size_t)P.lds_slots * (sizeof(V) + sizeof(double));
     // release the big host arrays; keep the small metadata
     std::vector<V>().swap(P.vals);
     std::vector<uint16_t>().swap(P.slots);
@@ -737,6 +743,39 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
   return r;
 }
 
+// how many workgroups of the tile kernel are co-resident on a CU for the LDS
+// budget the options ask for: the persistent grid is sized to exactly one
+// resident wave of workgroups (a workgroup that has to wait for a slot would
+// run as a second round and double the launch time)
+template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
+  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0>;
+  HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k, BLOCK, lds));
+  return 0;
+}
+template <typename V> static int query_residency(cfs_plan::Options &po) {
+  int block = po.block_threads > 0 ? po.block_threads : 256;
+  int slots = po.max_slots > 0 ? po.max_slots : 2560;
+  const int slot_bytes = (int)sizeof(V) + 8;
+  if (slots > 160 * 1024 / slot_bytes) slots = 160 * 1024 / slot_bytes;
+  if (slots > cfs_plan::kSlotsPerThread * block) slots = cfs_plan::kSlotsPerThread * block;
+  if (slots < 64) slots = 64;
+  const size_t lds = (size_t)((slots + 63) / 64 * 64) * slot_bytes;
+  int nb = 0, rc;
+  switch (block) {
+  case 256: rc = residency_one<V, 256>(lds, &nb); break;
+  case 512: rc = residency_one<V, 512>(lds, &nb); break;
+  case 1024: rc = residency_one<V, 1024>(lds, &nb); break;
+  default: return 0; // build_plan reports the bad block size
+  }
+  if (rc) return rc;
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, g_device));
+  po.wg_per_cu = nb > 0 ? nb : 1;
+  po.num_cus = prop.multiProcessorCount;
+  return 0;
+}
+
 template <typename V>
 static int sym_create(int n, const int *rowptr, const int *colind, const V *values,
                       int nranks, int rank, const int *row_splits,
@@ -752,8 +791,13 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   if (rc) return rc;
   auto *m = new SymMatrix<V>();
   m->value_bytes = (int)sizeof(V);
+  cfs_plan::Options po = to_opts(opt);
+  if ((rc = query_residency<V>(po))) {
+    delete m;
+    return rc;
+  }
   if (!cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                               nranks > 1 ? row_splits : nullptr, to_opts(opt), m->P)) {
+                               nranks > 1 ? row_splits : nullptr, po, m->P)) {
     std::string e = m->P.error;
     delete m;
     return set_err(CFS_HIP_ERR_UNSUPPORTED, e);

@@ -44,6 +44,8 @@ struct Options {
   int max_tile_nnz = 0;
   int block_threads = 0;
   int flags = 0;
+  int wg_per_cu = 0; // measured residency of the tile kernel (0 = estimate)
+  int num_cus = 0;   // compute units of the device (0 = 256, MI355X)
 };
 
 // one tile = one pass of a workgroup through prologue / slices / epilogue
@@ -69,7 +71,6 @@ struct SliceMeta {
 constexpr int kLanes = 64;
 constexpr int kPacket = 4;            // diagonals per packet
 constexpr int kAlignEntries = 8;      // slice streams start on 8-entry bounds
-constexpr int kMaxSlotsHard = 10240;  // 16 B/slot fp64 -> 160 KiB LDS
 constexpr int kSlotsPerThread = 10;   // LDS slots one thread fills/flushes (registers)
 
 template <typename V> struct SymPlan {
@@ -160,7 +161,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
     return false;
   }
   const int rows = re - rb;
-  const int slot_bytes = 2 * (int)sizeof(V);
+  const int slot_bytes = (int)sizeof(V) + 8; // x window in V, y window always fp64
   const int hard_slots = 160 * 1024 / slot_bytes;
   int max_slots = opt.max_slots > 0 ? opt.max_slots : 2560;
   if (max_slots > hard_slots) max_slots = hard_slots;
@@ -203,9 +204,14 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
   // never straddle a chunk.
   {
     const int64_t lds_budget = (int64_t)max_slots * slot_bytes;
-    int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / lds_budget, 2048 / block);
+    // co-resident workgroups per CU: LDS, the 2048-thread limit and -- the tile
+    // kernel needs ~100-128 VGPRs -- 4 waves per SIMD; the creator passes the
+    // occupancy the runtime reports for the real kernel when a device is there
+    int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / lds_budget, (4 * 4 * 64) / block);
+    if (opt.wg_per_cu > 0) wg_per_cu = opt.wg_per_cu;
     if (wg_per_cu < 1) wg_per_cu = 1;
-    int ngroups = 256 * wg_per_cu;
+    const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
+    int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
     int by_rows = ((rows + 63) / 64 + 7) / 8 * 8;
     if (ngroups > by_rows) ngroups = by_rows;
     if (ngroups < 8) ngroups = 8;

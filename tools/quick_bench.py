@@ -11,8 +11,12 @@ configs = sys.argv[3:] or ["2560,256"]
 t = time.time()
 n, rp, ci, va, low = synth.generate(name, scale)
 print(f"gen {name} n={n} nnz_full={rp[-1]} nnz_low={low} {time.time()-t:.1f}s", flush=True)
-x = torch.from_numpy(synth.make_x(n)).cuda()
-y = torch.empty(n, dtype=torch.float64, device="cuda")
+import os
+f32 = os.environ.get("QB_DTYPE", "f64") == "f32"
+if f32:
+    va = va.astype(np.float32)
+x = torch.from_numpy(synth.make_x(n, 42, np.float32 if f32 else np.float64)).cuda()
+y = torch.empty(n, dtype=x.dtype, device="cuda")
 for cfg in configs:
     slots, block = (int(v) for v in cfg.split(",")[:2])
     mtn = int(cfg.split(",")[2]) if cfg.count(",") >= 2 else 0
