@@ -49,7 +49,7 @@ SYMBOLS = [
     "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_spmv",
     "cfs_hip_sym_spmv_async", "cfs_hip_sym_shard_send_counts", "cfs_hip_sym_shard_send_rows",
     "cfs_hip_sym_shard_set_recv", "cfs_hip_sym_spmv_local_async",
-    "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_plan_check_f64",
+    "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_plan_check_f64",
     "cfs_hip_sym_plan_check_f32", "cfs_hip_sym_plan_send_info_f64", "cfs_hip_csr_create_f64", "cfs_hip_csr_create_f32",
     "cfs_hip_csr_spmv", "cfs_hip_csr_spmv_async", "cfs_hip_csr_destroy",
     "cfs_hip_event_create", "cfs_hip_event_record", "cfs_hip_event_elapsed_ms",
@@ -105,6 +105,7 @@ def load():
     lib.cfs_hip_sym_recv_fold_async.argtypes = [vp, vp, vp, vp]
     lib.cfs_hip_sym_spmv_phases_async.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     lib.cfs_hip_sym_get_stats.argtypes = [vp, C.POINTER(SymStats)]
+    lib.cfs_hip_sym_debug_timeline.argtypes = [vp, vp, vp, vp, C.c_int, ip]
     lib.cfs_hip_csr_spmv.argtypes = [vp, vp, vp]
     lib.cfs_hip_csr_spmv_async.argtypes = [vp, vp, vp, vp]
     lib.cfs_hip_csr_destroy.argtypes = [vp]

@@ -9,6 +9,7 @@
 // Written for gfx950 only; compile with hipcc --offload-arch=gfx950.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,7 +52,7 @@ static int ensure_init() {
 template <typename V> struct SymDev {
   const Tile *tiles;
   const int32_t *group_ptr;
-  const int32_t *halo_col;
+  const int32_t *slot_col; // original column of every slot of every tile
   const uint32_t *rowinfo;
   const V *diag;
   const uint2 *slice_meta; // {entry offset inside the tile, lanes of packet 0}
@@ -147,21 +148,22 @@ __device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigne
 template <typename V, int BLOCK, int MODE>
 __global__ void __launch_bounds__(BLOCK)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const int32_t *__restrict__ a_group_ptr,
-                        const int32_t *__restrict__ a_halo_col,
+                        const int32_t *__restrict__ a_slot_col,
                         const uint32_t *__restrict__ a_rowinfo, const V *__restrict__ a_diag,
                         const uint2 *__restrict__ a_slice_meta, const V *__restrict__ a_vals,
                         const uint16_t *__restrict__ a_slots, const V *__restrict__ a_cvals,
                         const uint16_t *__restrict__ a_crows,
                         const uint16_t *__restrict__ a_ccols, V *__restrict__ a_strip,
                         const int a_row_begin, const int a_lds_slots,
-                        const V *__restrict__ x, V *__restrict__ y) {
+                        const V *__restrict__ x, V *__restrict__ y,
+                        unsigned long long *__restrict__ dbg) {
   // every array is a separate __restrict__ argument: read-only metadata at
   // wave-uniform addresses then becomes scalar loads (s_load), off the vector
   // memory counter the matrix stream is pipelined on
   struct {
     const Tile *__restrict__ tiles;
     const int32_t *__restrict__ group_ptr;
-    const int32_t *__restrict__ halo_col;
+    const int32_t *__restrict__ slot_col;
     const uint32_t *__restrict__ rowinfo;
     const V *__restrict__ diag;
     const uint2 *__restrict__ slice_meta;
@@ -172,8 +174,11 @@ __global__ void __launch_bounds__(BLOCK)
     const uint16_t *__restrict__ ccols;
     V *__restrict__ strip;
     int row_begin, lds_slots;
-  } d = {a_tiles, a_group_ptr, a_halo_col, a_rowinfo, a_diag, a_slice_meta, a_vals,
+  } d = {a_tiles, a_group_ptr, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_vals,
          a_slots, a_cvals, a_crows, a_ccols, a_strip, a_row_begin, a_lds_slots};
+  // slice ticket counter of the current tile (16 B so the dynamic region below
+  // stays 16-byte aligned)
+  __shared__ __align__(16) int cfs_ticket[4];
   extern __shared__ __align__(16) unsigned char cfs_smem[];
   double *yl = reinterpret_cast<double *>(cfs_smem); // fp64 first: keeps 8-B alignment
   V *xl = reinterpret_cast<V *>(yl + d.lds_slots);
@@ -188,6 +193,9 @@ __global__ void __launch_bounds__(BLOCK)
   const int nper = gridDim.x >> 3;
   const int g = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
   const int t0 = d.group_ptr[g], t1 = d.group_ptr[g + 1];
+  // developer timeline (cfs_hip_sym_debug_timeline): 100 MHz wall clock stamps of
+  // this workgroup's phases; dbg is NULL in every product launch
+  if (dbg && tid == 0) dbg[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
 
   // x window of a tile, gathered into registers with every load in flight at
   // once (two round trips: halo columns, then x).  Under a saturated memory
@@ -197,21 +205,15 @@ __global__ void __launch_bounds__(BLOCK)
   constexpr int U = cfs_plan::kSlotsPerThread;
   V xr[U];
   auto gather_x = [&](const Tile &tn) {
-    // every load is unconditional (clamped index, select afterwards): a load
-    // under a divergent branch would make the compiler drain vmcnt before the
-    // other side of the branch may write the same register
+    // every load is unconditional (clamped index): a load under a divergent
+    // branch would make the compiler drain vmcnt before the other side of the
+    // branch may write the same register.  Own rows go through the slot table
+    // too: tiles are clusters of the matrix graph, not runs of consecutive rows.
     int idx[U];
-    const int nh = tn.nslots - tn.nown;
 #pragma unroll
     for (int k = 0; k < U; ++k) {
-      const int i = tid + k * BLOCK;
-      const int hi = min(max(i - tn.nown, 0), max(nh - 1, 0));
-      idx[k] = d.halo_col[tn.halo_off + hi]; // halo_col is padded by one entry
-    }
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const int i = tid + k * BLOCK;
-      idx[k] = i < tn.nown ? tn.row0 + i : (i < tn.nslots ? idx[k] : tn.row0);
+      const int i = min(tid + k * BLOCK, tn.nslots - 1);
+      idx[k] = d.slot_col[tn.slot_off + i]; // slot_col is padded by one entry
     }
     if (MODE != 4) {
 #pragma unroll
@@ -222,12 +224,12 @@ __global__ void __launch_bounds__(BLOCK)
     }
   };
   if (t0 < t1) gather_x(d.tiles[t0]);
-  int prev_nown = 0, prev_nslots = 0, prev_lrow0 = 0, prev_halo_off = 0;
+  int prev_nown = 0, prev_nslots = 0, prev_slot_off = 0, prev_halo_off = 0;
 
   for (int ti = t0; ti < t1; ++ti) {
     const Tile t = d.tiles[ti];
     const int nown = t.nown, nslots = t.nslots;
-    const int lrow0 = t.row0 - d.row_begin;
+    const int vrow0 = t.vrow_off, nvr = t.nvrows;
     const V *tv = d.vals + t.nnz_off;
     const uint16_t *ts = d.slots + t.nnz_off;
     const uint2 *smeta = d.slice_meta + t.slice_base;
@@ -235,8 +237,11 @@ __global__ void __launch_bounds__(BLOCK)
 
     // the matrix stream does not depend on x: request this wave's first slice
     // header and head packet (and its first COO packet) before touching the LDS
-    // windows.  Slice metadata are scalar loads kept two slices ahead.
-    int s = wave;
+    // windows.  Slices are handed out dynamically (they are sorted by cost, so
+    // this is longest-first scheduling over the waves): a wave starts with
+    // slices `wave` and `wave + NW` and draws every later one from an LDS
+    // ticket counter one slice ahead of its use.
+    int s = wave, s_n = wave + NW;
     uint2 meta_c = make_uint2(0u, 0u), meta_n = make_uint2(0u, 0u);
     uint32_t info_c = 0u;
     V dg_c = V(0);
@@ -245,12 +250,12 @@ __global__ void __launch_bounds__(BLOCK)
     N.c = make_ushort4(0, 0, 0, 0);
     if (s < nsl) {
       meta_c = smeta[s];
-      if (s + NW < nsl) meta_n = smeta[s + NW];
-      const int p0 = s * 64 + lane, q0 = min(p0, nown - 1);
-      const uint32_t i0 = d.rowinfo[lrow0 + q0]; // unconditional, clamped
-      const V d0 = d.diag[lrow0 + q0];
-      info_c = p0 < nown ? i0 : 0u;
-      dg_c = p0 < nown ? d0 : V(0);
+      if (s_n < nsl) meta_n = smeta[s_n];
+      const int p0 = s * 64 + lane, q0 = min(p0, nvr - 1);
+      const uint32_t i0 = d.rowinfo[vrow0 + q0]; // unconditional, clamped
+      const V d0 = d.diag[vrow0 + q0];
+      info_c = p0 < nvr ? i0 : 0u;
+      dg_c = p0 < nvr ? d0 : V(0);
       fetch_packet(N, tv, ts, meta_c.x, (int)meta_c.y, lane);
     }
     const int ncp = (t.ncoo + 255) >> 8; // COO packets of this tile
@@ -264,11 +269,15 @@ __global__ void __launch_bounds__(BLOCK)
     }
     // flush the previous tile's y window and refill both windows.  A thread
     // owns the same slot indices in both steps, so no barrier is needed between.
+    int yidx[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) // own rows' y positions (original numbering, block-local)
+      yidx[k] = d.slot_col[prev_slot_off + min(tid + k * BLOCK, max(prev_nown - 1, 0))] - d.row_begin;
 #pragma unroll
     for (int k = 0; k < U; ++k) {
       const int i = tid + k * BLOCK;
       if (MODE != 4) {
-        if (i < prev_nown) y[prev_lrow0 + i] = (V)yl[i];
+        if (i < prev_nown) y[yidx[k]] = (V)yl[i];
         else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = (V)yl[i];
       }
       if (i < nslots) {
@@ -276,25 +285,35 @@ __global__ void __launch_bounds__(BLOCK)
         yl[i] = 0.0;
       }
     }
+    if (tid == 0) cfs_ticket[0] = 2 * NW;
     __syncthreads();
+    if (dbg && tid == 0 && ti == t0) dbg[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
-    for (; MODE != 3 && s < nsl; s += NW) {
+    while (MODE != 3 && s < nsl) {
       const uint32_t info = info_c;
       const V dg = dg_c;
       uint32_t off = meta_c.x;
       int cnt = (int)meta_c.y;
       Pkt<V> A = N;
-      const bool have_next = s + NW < nsl;
+      // ticket for the slice after next (its metadata is a scalar load that
+      // lands long before it is needed)
+      int s_nn = 0;
+      if (lane == 0) s_nn = atomicAdd(&cfs_ticket[0], 1);
+      s_nn = __builtin_amdgcn_readfirstlane(s_nn);
+      const bool have_next = s_n < nsl;
       if (have_next) { // next slice: header + head packet, a whole slice ahead
-        const int pn = (s + NW) * 64 + lane, qn = min(pn, nown - 1);
-        const uint32_t in_ = d.rowinfo[lrow0 + qn]; // unconditional, clamped
-        const V dn = d.diag[lrow0 + qn];
-        info_c = pn < nown ? in_ : 0u;
-        dg_c = pn < nown ? dn : V(0);
+        const int pn = s_n * 64 + lane, qn = min(pn, nvr - 1);
+        const uint32_t in_ = d.rowinfo[vrow0 + qn]; // unconditional, clamped
+        const V dn = d.diag[vrow0 + qn];
+        info_c = pn < nvr ? in_ : 0u;
+        dg_c = pn < nvr ? dn : V(0);
         fetch_packet(N, tv, ts, meta_n.x, (int)meta_n.y, lane);
       }
       meta_c = meta_n;
-      if (s + 2 * NW < nsl) meta_n = smeta[s + 2 * NW];
+      if (s_nn < nsl) meta_n = smeta[s_nn];
+      const int s_cur = s;
+      s = s_n;
+      s_n = s_nn;
 
       const int r = info & 0xffffu;
       const int a = (int)(info >> 16); // packets of this lane's row
@@ -325,7 +344,7 @@ __global__ void __launch_bounds__(BLOCK)
       } else if (amax - g == 1) {
         if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
       }
-      if (s * 64 + lane < nown) atomicAdd(&yl[r], (double)fma(dg, xi, acc));
+      if (s_cur * 64 + lane < nvr) atomicAdd(&yl[r], (double)fma(dg, xi, acc));
     }
     // COO leftovers: packet p = wave, wave + NW, ...; the first one was requested
     // at the top of the tile
@@ -342,21 +361,24 @@ __global__ void __launch_bounds__(BLOCK)
       if (e0 + 2 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[2], Qr.z, Q.c.z);
       if (e0 + 3 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[3], Qr.w, Q.c.w);
     }
+    if (dbg && lane == 0 && ti + 1 == t1) dbg[blockIdx.x * 8 + 4 + min(wave, 3)] = __builtin_amdgcn_s_memrealtime();
     if (ti + 1 < t1) gather_x(d.tiles[ti + 1]); // lands behind the barrier + flush
     prev_nown = nown;
     prev_nslots = nslots;
-    prev_lrow0 = lrow0;
+    prev_slot_off = t.slot_off;
     prev_halo_off = t.halo_off;
     __syncthreads();
   }
+  if (dbg && tid == 0) dbg[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
   // flush the last tile
 #pragma unroll
   for (int k = 0; k < U; ++k) {
     const int i = tid + k * BLOCK;
     if (MODE == 4) break;
-    if (i < prev_nown) y[prev_lrow0 + i] = (V)yl[i];
+    if (i < prev_nown) y[d.slot_col[prev_slot_off + i] - d.row_begin] = (V)yl[i];
     else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = (V)yl[i];
   }
+  if (dbg && tid == 0) dbg[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // halo fold: y[dst] += sum of the strip entries aimed at dst, in fixed order
@@ -439,19 +461,21 @@ struct cfs_hip_sym_s {
   virtual const std::vector<int32_t> &send_rows() = 0;
   virtual int n() = 0;
   virtual int rows() = 0;
+  virtual int timeline(void *y, const void *x, unsigned long long *host, int cap, int *ngroups) = 0;
   // staging for host-pointer callers
   DevBuf xstage, ystage;
 };
 
 template <typename V> struct SymMatrix : cfs_hip_sym_s {
   SymPlan<V> P; // big arrays released after upload
-  DevBuf tiles, group_ptr, halo_col, rowinfo, diag, slice_meta, vals, slots, strip;
+  DevBuf tiles, group_ptr, slot_col, rowinfo, diag, slice_meta, vals, slots, strip;
   DevBuf cvals, crows, ccols;
   DevBuf fold_row, fold_ptr, fold_idx, send_ptr, send_idx;
   DevBuf rfold_row, rfold_ptr, rfold_idx;
   SymDev<V> dev{};
   int nfold = 0, nsend = 0, nrfold = 0;
-  int ablate_mode = 0; // cfs_hip_options.flags & 3 (timing-only ablations)
+  int ablate_mode = 0; // cfs_hip_options.flags & 7 (timing-only ablations)
+  unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
   size_t lds_bytes = 0;
   int64_t halo_slots = 0, stream_len = 0, nslices = 0, coo_len = 0;
 
@@ -461,7 +485,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   if ((rc = buf.upload(vec.data(), vec.size() * sizeof(vec[0])))) return rc;
     UP(tiles, P.tiles)
     UP(group_ptr, P.group_ptr)
-    UP(halo_col, P.halo_col)
+    UP(slot_col, P.slot_col)
     UP(rowinfo, P.rowinfo)
     UP(diag, P.diag)
     UP(slice_meta, P.slice_meta)
@@ -470,7 +494,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(ccols, P.ccols)
     UP(vals, P.vals)
     UP(slots, P.slots)
-    UP(fold_row, P.fold_row)
+    UP(fold_row, P.fold_dst)
     UP(fold_ptr, P.fold_ptr)
     UP(fold_idx, P.fold_idx)
     UP(send_ptr, P.send_ptr)
@@ -481,11 +505,11 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     stream_len = P.stream_len;
     nslices = (int64_t)P.slice_meta.size();
     coo_len = P.coo_len;
-    nfold = (int)P.fold_row.size();
+    nfold = (int)P.fold_dst.size();
     nsend = (int)P.send_row.size();
     dev.tiles = (const Tile *)tiles.p;
     dev.group_ptr = (const int32_t *)group_ptr.p;
-    dev.halo_col = (const int32_t *)halo_col.p;
+    dev.slot_col = (const int32_t *)slot_col.p;
     dev.rowinfo = (const uint32_t *)rowinfo.p;
     dev.diag = (const V *)diag.p;
     dev.slice_meta = (const uint2 *)slice_meta.p;
@@ -536,29 +560,29 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     const int mode = ablate_mode;
     if (mode == 1)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 1>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else if (mode == 2)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 2>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else if (mode == 3)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 3>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else if (mode == 4)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 4>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 0>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.halo_col, dev.rowinfo, dev.diag,
+                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
   }
 
   int spmv_local(void *yv, const void *xv, void *sendv, hipStream_t st, int phases) override {
@@ -632,17 +656,34 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     o->lds_bytes = (int64_t)lds_bytes;
     o->bytes_algorithmic = P.nnz_low * (4 + s) + rows_ * (4 + 3 * s);
     o->bytes_streamed = stream_len * (s + 2) + coo_len * (s + 4) + rows_ * (4 + 3 * s) +
-                        halo_slots * (4 + 2 * s)            /* halo_col, x, strip st */
+                        halo_slots * (4 + 2 * s) + rows_ * 8 /* slot_col, x, strip st */
                         + halo_slots * (4 + s)              /* fold: idx + strip ld  */
                         + (int64_t)(nfold + nsend) * (8 + 2 * s) + nslices * 8 +
                         (int64_t)P.tiles.size() * (int64_t)sizeof(Tile);
-    o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + halo_col.bytes +
+    o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + slot_col.bytes +
                                 rowinfo.bytes + diag.bytes + slice_meta.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +
                                 slots.bytes + strip.bytes + fold_row.bytes + fold_ptr.bytes +
                                 fold_idx.bytes + send_ptr.bytes + send_idx.bytes);
   }
   const std::vector<int32_t> &send_counts() override { return P.send_counts; }
   const std::vector<int32_t> &send_rows() override { return P.send_row; }
+  int timeline(void *y, const void *x, unsigned long long *host, int cap, int *ng) override {
+    *ng = P.ngroups;
+    if (cap < P.ngroups * 8) return set_err(CFS_HIP_ERR_ARG, "buffer too small: need 8 words per group");
+    DevBuf b;
+    int rc = b.alloc((size_t)P.ngroups * 8 * sizeof(unsigned long long));
+    if (rc) return rc;
+    HIPCHK(hipMemset(b.p, 0, b.bytes));
+    for (int it = 0; it < 3; it++) { // warm, then the recorded launch
+      dbg_buf = it == 2 ? (unsigned long long *)b.p : nullptr;
+      rc = spmv_local(y, x, nullptr, (hipStream_t)0, CFS_HIP_PHASE_TILES);
+      dbg_buf = nullptr;
+      if (rc) return rc;
+    }
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host, b.p, b.bytes, hipMemcpyDeviceToHost));
+    return 0;
+  }
   int n() override { return P.n; }
   int rows() override { return P.row_end - P.row_begin; }
 };
@@ -739,6 +780,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     r.max_tile_nnz = o->max_tile_nnz;
     r.block_threads = o->block_threads;
     r.flags = o->flags;
+    r.reorder = !(o->flags & CFS_HIP_FLAG_NO_REORDER);
   }
   return r;
 }
@@ -755,9 +797,9 @@ template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
 }
 template <typename V> static int query_residency(cfs_plan::Options &po) {
   int block = po.block_threads > 0 ? po.block_threads : 256;
-  int slots = po.max_slots > 0 ? po.max_slots : 2560;
+  int slots = po.max_slots > 0 ? po.max_slots : cfs_plan::kDefaultSlots;
   const int slot_bytes = (int)sizeof(V) + 8;
-  if (slots > 160 * 1024 / slot_bytes) slots = 160 * 1024 / slot_bytes;
+  if (slots > (160 * 1024 - 64) / slot_bytes) slots = (160 * 1024 - 64) / slot_bytes;
   if (slots > cfs_plan::kSlotsPerThread * block) slots = cfs_plan::kSlotsPerThread * block;
   if (slots < 64) slots = 64;
   const size_t lds = (size_t)((slots + 63) / 64 * 64) * slot_bytes;
@@ -917,6 +959,12 @@ int cfs_hip_sym_recv_fold_async(cfs_hip_sym_t h, void *y, const void *recv, void
   return h->recv_fold(y, recv, (hipStream_t)stream);
 }
 
+int cfs_hip_sym_debug_timeline(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
+                               unsigned long long *stamps, int capacity_words, int *ngroups) {
+  if (!h || !y_dev || !x_dev || !stamps || !ngroups) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  return h->timeline(y_dev, x_dev, stamps, capacity_words, ngroups);
+}
+
 int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out) {
   if (!h || !out) return set_err(CFS_HIP_ERR_ARG, "null argument");
   h->stats(out);
@@ -951,32 +999,45 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   rep->fold_rows = (int64_t)P.fold_row.size();
   rep->remote_vals = (int64_t)P.send_row.size();
   rep->decoded = (int64_t)r.size();
-  // (1) decoded triples == strict lower triangle of the owned rows (per-row
-  // multisets; order inside a row is preserved by construction)
+  // (1) decoded triples == strict lower triangle of the owned rows, as
+  // multisets of (row, col, value bits): clustering moves an entry to the row
+  // of its later end and back, and reorders entries inside rows
   int64_t bad = 0;
   {
-    std::vector<int64_t> pos(P.row_end - P.row_begin + 1, 0);
-    for (size_t k = 0; k < r.size(); k++) pos[r[k] - P.row_begin + 1]++;
-    for (size_t i = 1; i < pos.size(); i++) pos[i] += pos[i - 1];
-    std::vector<int32_t> dc(r.size());
-    std::vector<V> dv(r.size());
-    std::vector<int64_t> fill(pos.begin(), pos.end() - 1);
-    for (size_t k = 0; k < r.size(); k++) {
-      int64_t q = fill[r[k] - P.row_begin]++;
-      dc[q] = c[k];
-      dv[q] = v[k];
-    }
-    for (int i = P.row_begin; i < P.row_end; i++) {
-      int64_t q = pos[i - P.row_begin];
-      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-        if (colind[j] >= i) continue;
-        if (q >= pos[i - P.row_begin + 1] || dc[q] != colind[j] ||
-            memcmp(&dv[q], &values[j], sizeof(V)) != 0)
-          bad++;
-        q++;
+    struct Tr {
+      int32_t r, c;
+      uint64_t v;
+      bool operator<(const Tr &o) const {
+        return r != o.r ? r < o.r : (c != o.c ? c < o.c : v < o.v);
       }
-      if (q != pos[i - P.row_begin + 1]) bad++;
-    }
+      bool operator!=(const Tr &o) const { return r != o.r || c != o.c || v != o.v; }
+    };
+    auto bits = [](V x) {
+      uint64_t u = 0;
+      memcpy(&u, &x, sizeof(V));
+      return u;
+    };
+    std::vector<Tr> A, B;
+    A.reserve(r.size());
+    B.reserve(r.size());
+    for (size_t k = 0; k < r.size(); k++) A.push_back(Tr{r[k], c[k], bits(v[k])});
+    for (int i = P.row_begin; i < P.row_end; i++)
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+        if (colind[j] < i) B.push_back(Tr{i, colind[j], bits(values[j])});
+    std::sort(A.begin(), A.end());
+    std::sort(B.begin(), B.end());
+    if (A.size() != B.size()) bad += 1 + (int64_t)(A.size() > B.size() ? A.size() - B.size() : B.size() - A.size());
+    for (size_t k = 0; k < std::min(A.size(), B.size()); k++)
+      if (A[k] != B[k]) bad++;
+    // every own row appears exactly once in the slot table, at its diagonal slot
+    std::vector<char> seen_row(P.row_end - P.row_begin, 0);
+    for (const Tile &t : P.tiles)
+      for (int i = 0; i < t.nown; i++) {
+        int o = P.slot_col[t.slot_off + i] - P.row_begin;
+        if (o < 0 || o >= P.row_end - P.row_begin || seen_row[o]++) bad++;
+      }
+    for (char ch : seen_row)
+      if (!ch) bad++;
   }
   // (2) fold + send indices cover every strip entry exactly once and point at
   // a strip entry whose column is the destination row

@@ -44,6 +44,14 @@ struct Options {
   int max_tile_nnz = 0;
   int block_threads = 0;
   int flags = 0;
+  bool reorder = true; // cluster rows so that tiles are compact in every direction
+  int force_order = 0; // 0 = pick the order with fewer halo slots, 1 = natural, 2 = clustered
+  // relative work share of every persistent group (size = number of groups,
+  // any positive scale); empty = equal shares.  (Measured on MI355X: re-cutting
+  // the shares from per-workgroup finish times does not shorten the launch --
+  // workgroups of one CU finish in dispatch order whatever their shares, the
+  // CU total is what counts -- so nothing sets this today.)
+  std::vector<double> group_share;
   int wg_per_cu = 0; // measured residency of the tile kernel (0 = estimate)
   int num_cus = 0;   // compute units of the device (0 = 256, MI355X)
 };
@@ -53,15 +61,18 @@ struct Tile {
   int32_t row0;       // first own row (global index)
   int32_t nown;       // own rows = own slots [0, nown)
   int32_t nslots;     // nown + halo slots
-  int32_t nslices;    // ceil(nown / 64)
+  int32_t nslices;    // ceil(nvrows / 64)
   int32_t halo_off;   // offset of this tile's halo in halo_col[] and strip[]
   int32_t slice_base; // offset of this tile's slices in slice_meta[]
   int64_t nnz_off;    // offset of this tile's packet stream in vals[] / slots[]
   int32_t coo_off;    // offset of this tile's COO section in cvals/crows/ccols
   int32_t ncoo;       // leftover entries (len % 4 per row)
-  int32_t pad_[2];
+  int32_t slot_off;   // offset of this tile's slots in slot_col[]
+  int32_t vrow_off;   // offset of this tile's virtual rows in rowinfo[] / diag[]
+  int32_t nvrows;     // virtual rows (>= nown: long rows are split over lanes)
+  int32_t pad_[3];
 };
-static_assert(sizeof(Tile) == 48, "Tile must stay 48 bytes");
+static_assert(sizeof(Tile) == 64, "Tile must stay 64 bytes");
 
 struct SliceMeta {
   uint32_t off;  // entry offset of the slice's first packet inside its tile
@@ -71,6 +82,8 @@ struct SliceMeta {
 constexpr int kLanes = 64;
 constexpr int kPacket = 4;            // diagonals per packet
 constexpr int kAlignEntries = 8;      // slice streams start on 8-entry bounds
+constexpr int kDefaultSlots = 2496;    // 4 workgroups x (2496 x 16 B + 16 B) fit the 160 KiB of a CU
+constexpr int kStaticLds = 16;        // slice ticket counter
 constexpr int kSlotsPerThread = 10;   // LDS slots one thread fills/flushes (registers)
 
 template <typename V> struct SymPlan {
@@ -83,9 +96,13 @@ template <typename V> struct SymPlan {
   // schedule
   std::vector<Tile> tiles;
   std::vector<int32_t> group_ptr;   // [ngroups+1] tiles of persistent group g
-  std::vector<int32_t> halo_col;    // [H] global column of every halo slot
-  std::vector<uint32_t> rowinfo;    // [rows] sorted position -> local_row | npackets<<16
-  std::vector<V> diag;              // [rows] diagonal, in sorted position order
+  std::vector<int32_t> halo_col;    // [H] column of every halo slot (schedule space)
+  std::vector<int32_t> slot_col;    // [sum nslots + 1] ORIGINAL column of every slot
+  std::vector<int32_t> perm;        // [rows] schedule row -> original row (empty = identity)
+  std::vector<int32_t> fold_dst;    // [F] fold destination, original local row index
+  std::vector<uint32_t> rowinfo;    // [nvrows] virtual row -> local_row | npackets<<16
+  std::vector<V> diag;              // [nvrows] diagonal (first chunk of a row only)
+  int64_t nvrows = 0;
   std::vector<SliceMeta> slice_meta; // [S]
   std::vector<V> vals;              // [stream_len + pad] packet stream
   std::vector<uint16_t> slots;      // [stream_len + pad]
@@ -143,9 +160,10 @@ inline void balanced_splits(int n, const int *rowptr, const int *colind,
 // Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the full
 // CSR.  Returns false (plan.error set) when the matrix cannot be scheduled.
 template <typename V>
-bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
-                int nranks, int rank, const int *row_splits_in,
-                const Options &opt, SymPlan<V> &P) {
+bool build_plan_core(int n, const int *rowptr, const int *colind, const V *values,
+                     int nranks, int rank, const int *row_splits_in,
+                     const Options &opt, const std::vector<int32_t> *chunks_in,
+                     const std::vector<int32_t> *perm_in, SymPlan<V> &P) {
   P = SymPlan<V>();
   P.n = n;
   P.nranks = nranks;
@@ -162,8 +180,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
   }
   const int rows = re - rb;
   const int slot_bytes = (int)sizeof(V) + 8; // x window in V, y window always fp64
-  const int hard_slots = 160 * 1024 / slot_bytes;
-  int max_slots = opt.max_slots > 0 ? opt.max_slots : 2560;
+  const int hard_slots = (160 * 1024 - 64) / slot_bytes; // 16 B of static LDS (slice tickets)
+  int max_slots = opt.max_slots > 0 ? opt.max_slots : kDefaultSlots;
   if (max_slots > hard_slots) max_slots = hard_slots;
   if (max_slots > 65536) max_slots = 65536;
   if (max_slots < 64) max_slots = 64;
@@ -203,7 +221,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
   // workgroups as are co-resident), and only then into LDS-sized tiles that
   // never straddle a chunk.
   {
-    const int64_t lds_budget = (int64_t)max_slots * slot_bytes;
+    const int64_t lds_budget = (int64_t)((max_slots + 63) / 64 * 64) * slot_bytes + kStaticLds;
     // co-resident workgroups per CU: LDS, the 2048-thread limit and -- the tile
     // kernel needs ~100-128 VGPRs -- 4 waves per SIMD; the creator passes the
     // occupancy the runtime reports for the real kernel when a device is there
@@ -222,8 +240,17 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
                     (int64_t)(4 + 3 * sizeof(V)) + 2 * (int64_t)sizeof(V);
     std::vector<int32_t> chunk(ngroups + 1, re);
     chunk[0] = rb;
-    for (int g = 1; g < ngroups; g++) {
-      int64_t target = cost[rows] * g / ngroups;
+    if (chunks_in) {
+      ngroups = (int)chunks_in->size() - 1;
+      P.ngroups = ngroups;
+      chunk = *chunks_in;
+    }
+    std::vector<double> cumshare(ngroups + 1, 0.0);
+    for (int g = 0; g < ngroups; g++)
+      cumshare[g + 1] = cumshare[g] + ((int)opt.group_share.size() == ngroups
+                                           ? std::max(opt.group_share[g], 1e-9) : 1.0);
+    for (int g = 1; !chunks_in && g < ngroups; g++) {
+      int64_t target = (int64_t)((double)cost[rows] * (cumshare[g] / cumshare[ngroups]));
       int r = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
       if (r > rows) r = rows;
       if (rb + r < chunk[g - 1]) r = chunk[g - 1] - rb;
@@ -301,69 +328,111 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
   }
   const int T = (int)P.tiles.size();
 
-  // ---- offsets -------------------------------------------------------------
+  // ---- virtual rows: one lane each ----------------------------------------------
+  // A lane normally owns a whole row.  A row much longer than its neighbours
+  // (irregular degrees, e.g. ldoor) would leave one lane streaming alone for
+  // most of its slice, so such a row is split into chunks of at most `acap`
+  // packets; every chunk is a VIRTUAL ROW with its own lane, the chunks add
+  // their partial sums to the same LDS slot and only the first carries the
+  // diagonal.  Virtual rows are sorted by packet count (stable counting sort,
+  // descending): the lanes still active in packet g of a slice are a prefix.
+  struct VRow {
+    int32_t r, k0, a; // local row, first packet of the chunk, packets in the chunk
+  };
+  auto build_vrows = [&](const Tile &t, std::vector<VRow> &vr) {
+    vr.clear();
+    int64_t sum = 0;
+    for (int r = 0; r < t.nown; r++) sum += lcnt[t.row0 - rb + r] >> 2;
+    const int avg = (int)((sum + t.nown - 1) / std::max(1, (int)t.nown));
+    const int acap = std::max(8, 2 * avg);
+    std::vector<VRow> tmp;
+    int maxa = 0;
+    for (int r = 0; r < t.nown; r++) {
+      const int a = lcnt[t.row0 - rb + r] >> 2;
+      if (a <= acap) {
+        tmp.push_back(VRow{r, 0, a});
+        maxa = std::max(maxa, a);
+      } else {
+        const int parts = (a + acap - 1) / acap;
+        for (int q = 0, k0 = 0; q < parts; q++) {
+          const int ca = (a - k0 + (parts - q) - 1) / (parts - q); // even chunks
+          tmp.push_back(VRow{r, k0, ca});
+          maxa = std::max(maxa, ca);
+          k0 += ca;
+        }
+      }
+    }
+    std::vector<int32_t> cnt(maxa + 2, 0);
+    for (auto &v : tmp) cnt[maxa - v.a + 1]++;
+    for (int k = 0; k <= maxa; k++) cnt[k + 1] += cnt[k];
+    vr.resize(tmp.size());
+    for (auto &v : tmp) vr[cnt[maxa - v.a]++] = v;
+  };
+  std::vector<int64_t> tile_len(T, 0);
   {
-    int64_t halo = 0, slices = 0;
+    std::vector<int32_t> nv(T, 0);
+#pragma omp parallel
+    {
+      std::vector<VRow> vr;
+#pragma omp for schedule(dynamic, 8)
+      for (int ti = 0; ti < T; ti++) {
+        Tile &t = P.tiles[ti];
+        build_vrows(t, vr);
+        nv[ti] = (int32_t)vr.size();
+        t.nvrows = nv[ti];
+        t.nslices = (nv[ti] + kLanes - 1) / kLanes;
+        int64_t left = 0;
+        for (int r = 0; r < t.nown; r++) left += lcnt[t.row0 - rb + r] & 3;
+        t.ncoo = (int32_t)left;
+      }
+    }
+    // ---- offsets -------------------------------------------------------------
+    int64_t halo = 0, slices = 0, nsl = 0, nvr = 0;
     for (auto &t : P.tiles) {
       t.halo_off = (int32_t)halo;
       t.slice_base = (int32_t)slices;
+      t.slot_off = (int32_t)nsl;
+      t.vrow_off = (int32_t)nvr;
       halo += t.nslots - t.nown;
+      nsl += t.nslots;
       slices += t.nslices;
-      if (halo > 0x7fffffffLL) {
+      nvr += t.nvrows;
+      if (halo > 0x7fffffffLL || nsl > 0x7ffffff0LL || nvr > 0x7ffffff0LL) {
         P.error = "halo index overflow";
         return false;
       }
     }
     P.nhalo = halo;
-    P.halo_col.assign((size_t)halo + 1, 0); // +1: the kernel's clamped dummy read
+    P.halo_col.assign((size_t)halo + 1, 0);
+    P.slot_col.assign((size_t)nsl + 1, 0); // +1: the kernel's clamped dummy read
     P.slice_meta.assign((size_t)slices, SliceMeta{0u, 0u});
-    P.rowinfo.assign((size_t)rows, 0);
-    P.diag.assign((size_t)rows, V(0));
+    P.rowinfo.assign((size_t)nvr + 1, 0);
+    P.diag.assign((size_t)nvr + 1, V(0));
+    P.nvrows = nvr;
   }
 
-  // ---- per tile: length sort, stream sizes, then fill -------------------------
-  std::vector<int64_t> tile_len(T, 0);
-  // stable counting sort of a tile's local rows by packet count (len / 4),
-  // descending: the lanes still active in packet g are then a prefix
-  auto sort_rows = [&](const Tile &t, std::vector<int32_t> &perm) {
-    perm.resize(t.nown);
-    int maxa = 0;
-    for (int r = 0; r < t.nown; r++)
-      maxa = std::max(maxa, (int)lcnt[t.row0 - rb + r] >> 2);
-    std::vector<int32_t> cnt(maxa + 2, 0);
-    for (int r = 0; r < t.nown; r++) cnt[maxa - (lcnt[t.row0 - rb + r] >> 2) + 1]++;
-    for (int k = 0; k <= maxa; k++) cnt[k + 1] += cnt[k];
-    for (int r = 0; r < t.nown; r++) perm[cnt[maxa - (lcnt[t.row0 - rb + r] >> 2)]++] = r;
-  };
-#pragma omp parallel for schedule(dynamic, 8)
-  for (int ti = 0; ti < T; ti++) {
-    Tile &t = P.tiles[ti];
-    std::vector<int32_t> perm;
-    sort_rows(t, perm);
-    int64_t off = 0, left = 0;
-    for (int s = 0; s < t.nslices; s++) {
-      off = align_up(off, kAlignEntries);
-      int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nown);
-      uint32_t cnt0 = 0;
-      for (int p = p0; p < p1; p++) {
-        int len = lcnt[t.row0 - rb + perm[p]];
-        off += (int64_t)(len >> 2) * 4;
-        left += len & 3;
-        if (len >= 4) cnt0++;
+  // ---- per tile: stream sizes, then fill ------------------------------------------
+#pragma omp parallel
+  {
+    std::vector<VRow> vr;
+#pragma omp for schedule(dynamic, 8)
+    for (int ti = 0; ti < T; ti++) {
+      Tile &t = P.tiles[ti];
+      build_vrows(t, vr);
+      int64_t off = 0;
+      for (int s = 0; s < t.nslices; s++) {
+        off = align_up(off, kAlignEntries);
+        int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nvrows);
+        uint32_t cnt0 = 0;
+        P.slice_meta[t.slice_base + s].off = (uint32_t)off;
+        for (int p = p0; p < p1; p++) {
+          off += (int64_t)vr[p].a * 4;
+          if (vr[p].a >= 1) cnt0++;
+        }
+        P.slice_meta[t.slice_base + s].cnt0 = cnt0;
       }
-      // meta.off is set below (needs the offset BEFORE this slice's entries)
-      P.slice_meta[t.slice_base + s].cnt0 = cnt0;
+      tile_len[ti] = align_up(off, kAlignEntries);
     }
-    // second walk for the offsets (kept separate for clarity)
-    off = 0;
-    for (int s = 0; s < t.nslices; s++) {
-      off = align_up(off, kAlignEntries);
-      P.slice_meta[t.slice_base + s].off = (uint32_t)off;
-      int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nown);
-      for (int p = p0; p < p1; p++) off += (int64_t)(lcnt[t.row0 - rb + perm[p]] >> 2) * 4;
-    }
-    tile_len[ti] = align_up(off, kAlignEntries);
-    t.ncoo = (int32_t)left;
   }
   {
     int64_t off = 0, coo = 0;
@@ -392,7 +461,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
 #pragma omp parallel
   {
     std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
-    std::vector<int32_t> perm, hcols, lowj;
+    std::vector<int32_t> hcols, lowj;
+    std::vector<VRow> vr;
 #pragma omp for schedule(dynamic, 8)
     for (int ti = 0; ti < T; ti++) {
       const Tile &t = P.tiles[ti];
@@ -417,39 +487,40 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
       auto slot_of = [&](int c) {
         return (uint16_t)(c >= t.row0 ? c - t.row0 : colmap[c]);
       };
-      // positions (in the full CSR) of the lower entries of local row r, in
-      // stored order -- works whether or not the columns of a row ascend
+      // positions (in the CSR) of the lower entries of local row r, in stored
+      // order -- works whether or not the columns of a row ascend
       auto lower_of = [&](int r, std::vector<int32_t> &out) {
         out.clear();
         int i = t.row0 + r;
         for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
           if (colind[j] < i) out.push_back(j);
       };
-      sort_rows(t, perm);
+      build_vrows(t, vr);
       V *tv = P.vals.data() + t.nnz_off;
       uint16_t *ts = P.slots.data() + t.nnz_off;
       std::vector<std::vector<int32_t>> low(kLanes);
       for (int s = 0; s < t.nslices; s++) {
-        int p0 = s * kLanes, m = std::min(kLanes, (int)t.nown - p0);
+        int p0 = s * kLanes, m = std::min(kLanes, (int)t.nvrows - p0);
         int amax = 0;
         for (int l = 0; l < m; l++) {
-          int r = perm[p0 + l], i = t.row0 + r;
-          lower_of(r, low[l]);
-          int a = (int)low[l].size() >> 2;
-          amax = std::max(amax, a);
-          P.rowinfo[t.row0 - rb + p0 + l] = (uint32_t)r | ((uint32_t)a << 16);
+          const VRow &v = vr[p0 + l];
+          const int i = t.row0 + v.r;
+          lower_of(v.r, low[l]);
+          amax = std::max(amax, v.a);
+          P.rowinfo[t.vrow_off + p0 + l] = (uint32_t)v.r | ((uint32_t)v.a << 16);
           V d = V(0);
-          for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
-            if (colind[j] == i) d = values[j]; // last duplicate wins, like :1292
-          P.diag[t.row0 - rb + p0 + l] = d;
+          if (v.k0 == 0)
+            for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+              if (colind[j] == i) d = values[j]; // last duplicate wins, like :1292
+          P.diag[t.vrow_off + p0 + l] = d;
         }
         int64_t o = P.slice_meta[t.slice_base + s].off;
         for (int g = 0; g < amax; g++) {
           int cnt = 0;
-          while (cnt < m && ((int)low[cnt].size() >> 2) > g) cnt++;
+          while (cnt < m && vr[p0 + cnt].a > g) cnt++;
           for (int l = 0; l < cnt; l++)
             for (int j = 0; j < kPacket; j++) {
-              int q = low[l][g * kPacket + j];
+              int q = low[l][(vr[p0 + l].k0 + g) * kPacket + j];
               tv[o + packet_val_pos<V>(l, j, cnt)] = values[q];
               ts[o + packet_slot_pos(l, j)] = slot_of(colind[q]);
             }
@@ -533,6 +604,211 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values,
     for (auto &t : P.tiles) lds_slots = std::max(lds_slots, (int)t.nslots);
     P.lds_slots = (lds_slots + 63) / 64 * 64;
   }
+
+  // ---- schedule space -> original indices -------------------------------------
+  // the kernels address x and y in the caller's (original) numbering
+  {
+    auto orig = [&](int c) { return (perm_in && c >= rb) ? (*perm_in)[c - rb] : c; };
+    for (const Tile &t : P.tiles) {
+      for (int i = 0; i < t.nown; i++) P.slot_col[t.slot_off + i] = orig(t.row0 + i);
+      for (int h = 0; h < t.nslots - t.nown; h++)
+        P.slot_col[t.slot_off + t.nown + h] = orig(P.halo_col[t.halo_off + h]);
+    }
+    P.fold_dst.resize(P.fold_row.size());
+    for (size_t i = 0; i < P.fold_row.size(); i++)
+      P.fold_dst[i] = orig(P.fold_row[i] + rb) - rb;
+    if (perm_in) P.perm = *perm_in;
+  }
+  return true;
+}
+
+// Greedy graph growing: order the rows [rb, re) so that `ngroups` consecutive
+// chunks of (almost exactly) equal streamed cost are compact clusters of the
+// matrix graph -- the role METIS/KaHIP play for the reference's
+// partition_by_conflicts (csr_matrix.tpp:543-639): fewer columns shared
+// between partitions = fewer halo slots here, fewer conflicts there.  A
+// cluster grows breadth-first from a seed over unassigned rows until its cost
+// share is reached; what is left of its frontier seeds the next clusters, so
+// the clusters sweep through the graph like a wavefront.  O(nnz).
+// The cost of a cluster is exact: a row's stored (lower) entries in the new
+// order are its neighbours left of the block plus its neighbours assigned
+// before it, and the sum over a cluster does not depend on the order inside.
+template <typename V>
+void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, int ngroups,
+                  const std::vector<double> &share, std::vector<int32_t> &perm,
+                  std::vector<int32_t> &chunk) {
+  const int rows = re - rb;
+  const int64_t per_nz = (int64_t)sizeof(V) + 2, per_row = 4 + 5 * (int64_t)sizeof(V);
+  int64_t total = (int64_t)rows * per_row, inblock = 0;
+  for (int i = rb; i < re; i++)
+    for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+      int c = colind[j];
+      if (c < rb) total += per_nz;
+      else if (c < re && c != i) inblock++;
+    }
+  total += inblock / 2 * per_nz;
+  perm.clear();
+  perm.reserve(rows);
+  chunk.assign(ngroups + 1, re);
+  chunk[0] = rb;
+  std::vector<int32_t> state(rows, -1); // -1 free, -2-g queued for cluster g, >=0 assigned
+  std::vector<int32_t> bfs, seeds;
+  size_t seed_head = 0;
+  int next_free = 0;
+  int64_t cum = 0;
+  std::vector<double> cumshare(ngroups + 1, 0.0);
+  for (int g = 0; g < ngroups; g++)
+    cumshare[g + 1] = cumshare[g] + ((int)share.size() == ngroups ? std::max(share[g], 1e-9) : 1.0);
+  for (int g = 0; g < ngroups; g++) {
+    const int64_t target = (g == ngroups - 1)
+                               ? total + 1
+                               : (int64_t)((double)total * (cumshare[g + 1] / cumshare[ngroups]));
+    const size_t first = perm.size();
+    bfs.clear();
+    size_t head = 0;
+    while ((int)perm.size() < rows && (cum < target || g == ngroups - 1)) {
+      if (head == bfs.size()) { // need a seed: oldest frontier row, else next free row
+        int sd = -1;
+        while (seed_head < seeds.size()) {
+          int v = seeds[seed_head++];
+          if (state[v] < 0) {
+            sd = v;
+            break;
+          }
+        }
+        if (sd < 0) {
+          while (next_free < rows && state[next_free] >= 0) next_free++;
+          if (next_free >= rows) break;
+          sd = next_free;
+        }
+        state[sd] = -2 - g;
+        bfs.push_back(sd);
+      }
+      const int v = bfs[head++];
+      int low = 0;
+      const int i = rb + v;
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        const int c = colind[j];
+        if (c < rb) low++;
+        else if (c < re && c != i) {
+          const int u = c - rb;
+          if (state[u] >= 0) low++;
+          else if (state[u] != -2 - g) {
+            state[u] = -2 - g;
+            bfs.push_back(u);
+          }
+        }
+      }
+      state[v] = g;
+      perm.push_back(i);
+      cum += (int64_t)low * per_nz + per_row;
+    }
+    for (size_t k = head; k < bfs.size(); k++) { // unfinished frontier -> future seeds
+      state[bfs[k]] = -1;
+      seeds.push_back(bfs[k]);
+    }
+    std::sort(perm.begin() + first, perm.end()); // original order inside a cluster
+    chunk[g + 1] = rb + (int)perm.size();
+  }
+}
+
+// Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the full
+// CSR.  Returns false (plan.error set) when the matrix cannot be scheduled.
+template <typename V>
+bool build_plan(int n, const int *rowptr, const int *colind, const V *values, int nranks,
+                int rank, const int *row_splits_in, const Options &opt, SymPlan<V> &P) {
+  const int rb = row_splits_in ? row_splits_in[rank] : 0;
+  const int re = row_splits_in ? row_splits_in[rank + 1] : n;
+  const int rows = re - rb;
+  if (!opt.reorder || opt.force_order == 1 || rb < 0 || re > n || rows < 256)
+    return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
+                              nullptr, nullptr, P);
+  // number of persistent groups: same rule as the core
+  int block = opt.block_threads > 0 ? opt.block_threads : 256;
+  int max_slots = opt.max_slots > 0 ? opt.max_slots : kDefaultSlots;
+  const int slot_bytes = (int)sizeof(V) + 8;
+  max_slots = std::min(max_slots, std::min((160 * 1024 - 64) / slot_bytes, kSlotsPerThread * block));
+  max_slots = std::max(max_slots, 64);
+  int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / ((int64_t)((max_slots + 63) / 64 * 64) * slot_bytes + kStaticLds),
+                                         (4 * 4 * 64) / std::max(block, 64));
+  if (opt.wg_per_cu > 0) wg_per_cu = opt.wg_per_cu;
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
+  int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
+  int by_rows = ((rows + 63) / 64 + 7) / 8 * 8;
+  if (ngroups > by_rows) ngroups = by_rows;
+  if (ngroups < 8) ngroups = 8;
+
+  std::vector<int32_t> perm, chunk;
+  cluster_rows<V>(n, rowptr, colind, rb, re, ngroups, opt.group_share, perm, chunk);
+  std::vector<int32_t> inv(rows);
+  for (int p = 0; p < rows; p++) inv[perm[p] - rb] = rb + p;
+  // the lower triangle + diagonal in schedule space, from the ORIGINAL lower
+  // entries only (col <= row), each placed at (later, earlier) of its two ends
+  std::vector<int32_t> brp((size_t)n + 2, 0);
+  for (int i = rb; i < re; i++) {
+    const int pi = inv[i - rb];
+    for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+      const int c = colind[j];
+      if (c > i) continue;
+      const int pc = c >= rb ? inv[c - rb] : c;
+      brp[std::max(pi, pc) + 1]++;
+    }
+  }
+  for (int i = rb; i <= re; i++) brp[i + 1] += brp[i]; // rows < rb are empty
+  const int64_t bnnz = brp[re];
+  std::vector<int32_t> bci((size_t)bnnz + 1);
+  std::vector<V> bva((size_t)bnnz + 1);
+  {
+    std::vector<int32_t> fill(brp.begin(), brp.end());
+    for (int i = rb; i < re; i++) {
+      const int pi = inv[i - rb];
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        const int c = colind[j];
+        if (c > i) continue;
+        const int pc = c >= rb ? inv[c - rb] : c;
+        const int q = fill[std::max(pi, pc)]++;
+        bci[q] = std::min(pi, pc);
+        bva[q] = values[j];
+      }
+    }
+  }
+#pragma omp parallel
+  {
+    std::vector<std::pair<int32_t, V>> tmp;
+#pragma omp for schedule(dynamic, 512)
+    for (int p = rb; p < re; p++) { // columns ascending; duplicates keep their order
+      const int b = brp[p], e = brp[p + 1];
+      bool sorted = true;
+      for (int q = b + 1; q < e && sorted; q++) sorted = bci[q - 1] <= bci[q];
+      if (sorted) continue;
+      tmp.resize(e - b);
+      for (int q = b; q < e; q++) tmp[q - b] = {bci[q], bva[q]};
+      std::stable_sort(tmp.begin(), tmp.end(),
+                       [](const std::pair<int32_t, V> &x, const std::pair<int32_t, V> &y) {
+                         return x.first < y.first;
+                       });
+      for (int q = b; q < e; q++) {
+        bci[q] = tmp[q - b].first;
+        bva[q] = tmp[q - b].second;
+      }
+    }
+  }
+  if (!build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in,
+                          opt, &chunk, &perm, P))
+    return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
+                              nullptr, nullptr, P); // e.g. a cluster row too dense: natural order
+  // keep the clustered schedule only if it really has fewer halo slots (random
+  // sparsity has no locality to find; banded matrices are already compact)
+  if (opt.force_order != 2) {
+    std::vector<int32_t>().swap(bci);
+    std::vector<V>().swap(bva);
+    SymPlan<V> N;
+    if (build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
+                           nullptr, N) &&
+        N.nhalo + (int64_t)N.tiles.size() * 64 <= P.nhalo + (int64_t)P.tiles.size() * 64)
+      P = std::move(N);
+  }
   return true;
 }
 
@@ -567,7 +843,7 @@ bool set_recv(SymPlan<V> &P, int nrecv, const int *recv_rows) {
 }
 
 // Decode the device format back into (row, col, value) triples of the strict
-// lower triangle, walking it exactly as the kernel does (packets, jagged
+// lower triangle (original numbering), walking it exactly as the kernel does (packets, jagged
 // diagonals, slot -> column through the own range / halo map).  Structure
 // check for the CPU test-suite; performs no SpMV arithmetic.
 template <typename V>
@@ -587,10 +863,10 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
     // that the decoded order inside a row equals the stored order
     std::vector<std::vector<std::pair<int32_t, V>>> rows_out(t.nown);
     for (int s = 0; s < t.nslices; s++) {
-      int p0 = s * kLanes, m = std::min(kLanes, (int)t.nown - p0);
+      int p0 = s * kLanes, m = std::min(kLanes, (int)t.nvrows - p0);
       int a[kLanes], r[kLanes];
       for (int l = 0; l < kLanes; l++) {
-        uint32_t info = l < m ? P.rowinfo[t.row0 - rb + p0 + l] : 0;
+        uint32_t info = l < m ? P.rowinfo[t.vrow_off + p0 + l] : 0;
         r[l] = info & 0xffff;
         a[l] = info >> 16;
       }
@@ -615,10 +891,12 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
           {slot_col(cc[pk * 256 + packet_slot_pos(l, j)]),
            cv[pk * 256 + packet_val_pos<V>(l, j)]});
     }
+    auto orig = [&](int c) { return (!P.perm.empty() && c >= rb) ? P.perm[c - rb] : c; };
     for (int rr = 0; rr < t.nown; rr++)
       for (auto &e : rows_out[rr]) {
-        row.push_back(t.row0 + rr);
-        col.push_back(e.first);
+        const int a = orig(t.row0 + rr), b = orig(e.first);
+        row.push_back(std::max(a, b)); // back to the caller's lower orientation
+        col.push_back(std::min(a, b));
         val.push_back(e.second);
       }
   }

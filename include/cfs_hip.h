@@ -79,6 +79,9 @@ typedef struct {
  * 2 = no LDS traffic at all, 3 = LDS windows only (no matrix stream),
  * 4 = matrix stream only (no x gather / y flush)                             */
 #define CFS_HIP_FLAG_ABLATE_MASK 7
+/* keep rows in their given order (tiles = runs of consecutive rows) instead of
+ * clustering the matrix graph first (the default, fewer halo columns)        */
+#define CFS_HIP_FLAG_NO_REORDER 8
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->
@@ -174,6 +177,14 @@ typedef struct {
   int64_t device_bytes; /* device memory held by the handle               */
 } cfs_hip_sym_stats;
 int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out);
+/* developer diagnostic: one extra launch of the tile kernel that records, per
+ * persistent workgroup (in blockIdx order), 8 words of 100 MHz wall-clock
+ * stamps: [0] start, [1] first x window ready, [2] slices done, [3] end,
+ * [4..7] end of the last tile's slices for waves 0..3.  Not used by any product
+ * path; tools/timeline.py reads it.                                          */
+int cfs_hip_sym_debug_timeline(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
+                               unsigned long long *stamps, int capacity_words,
+                               int *ngroups);
 
 /* ---- host-only self-check of the tile schedule (needs no GPU): builds the
  *      schedule tune() would upload, decodes it back to (row, col, value)

@@ -72,9 +72,10 @@ def test_schedule_encodes_the_lower_triangle(name, scale, dtype):
 
 @pytest.mark.parametrize("slots,block", [(64, 256), (128, 512), (777, 256), (2560, 512),
                                          (5120, 1024), (10240, 1024)])
-def test_schedule_options(slots, block):
+@pytest.mark.parametrize("flags", [0, 8])
+def test_schedule_options(slots, block, flags):
     n, rp, ci, va, low = synth.generate("pwtk", 0.05)
-    rep = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(slots, 0, block))
+    rep = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(slots, 0, block, flags))
     assert rep["mismatches"] == 0 and rep["decoded"] == low
     assert rep["lds_slots"] <= max(64, (min(slots, 10 * block) + 63) // 64 * 64)
 
@@ -108,9 +109,13 @@ def test_dense_row_is_rejected_not_mangled():
     L[n - 1, :n - 1] = 1.0  # arrow: last row touches every column
     A = (L + L.T + sp.identity(n)).tocsr()
     A.sort_indices()
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
     with pytest.raises(_lib.CfsHipError, match="dense row"):
-        cfs.plan_check(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data,
-                       options=cfs.make_options(max_slots=128))
+        cfs.plan_check(n, rp, ci, A.data, options=cfs.make_options(max_slots=128, flags=8))
+    # with clustering (the default) the hub row is numbered early and its entries
+    # are stored at their other ends: the arrow becomes schedulable
+    rep = cfs.plan_check(n, rp, ci, A.data, options=cfs.make_options(max_slots=128))
+    assert rep["mismatches"] == 0 and rep["decoded"] == n - 1
 
 
 @pytest.mark.parametrize("nranks", [2, 3, 8])
