@@ -408,22 +408,68 @@ __global__ void __launch_bounds__(256)
   send[i] = s;
 }
 
-// general CSR: LPR lanes per row, shuffle reduction inside the sub-group
-template <typename V, int LPR>
+// general CSR, streaming form: a workgroup owns a block of consecutive rows whose
+// nonzeros fit its LDS product buffer; it streams colind/values fully coalesced
+// (4 independent loads per thread in flight), stores a_ij * x_j to LDS, then
+// every row is summed from LDS by CSR_RT lanes in stored order groups.  Rows
+// longer than the buffer get a block of their own and fall back to a
+// whole-workgroup strided sum.
+constexpr int kCsrNnz = 4096; // products per workgroup (32 KiB fp64)
+template <typename V>
 __global__ void __launch_bounds__(256)
-    cfs_csr_kernel(int nrows, const int32_t *__restrict__ rowptr,
-                   const int32_t *__restrict__ colind, const V *__restrict__ values,
-                   const V *__restrict__ x, V *__restrict__ y) {
-  const int gtid = blockIdx.x * 256 + threadIdx.x;
-  const int row = gtid / LPR, sub = gtid % LPR;
-  V acc = V(0);
-  if (row < nrows) {
-    const int b = rowptr[row], e = rowptr[row + 1];
-    for (int j = b + sub; j < e; j += LPR) acc = fma(values[j], x[colind[j]], acc);
-  }
+    cfs_csr_stream_kernel(const int32_t *__restrict__ blk_row, int nblocks,
+                          const int32_t *__restrict__ rowptr,
+                          const int32_t *__restrict__ colind, const V *__restrict__ values,
+                          const V *__restrict__ x, V *__restrict__ y) {
+  __shared__ V prod[kCsrNnz];
+  __shared__ V part[256];
+  const int tid = threadIdx.x;
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int r0 = blk_row[b], r1 = blk_row[b + 1];
+    const int p0 = rowptr[r0], p1 = rowptr[r1];
+    const int n = p1 - p0;
+    if (n <= kCsrNnz) {
+      for (int i = tid; i < n; i += 1024) { // 4 independent coalesced loads in flight
+        V v[4];
+        int c[4];
 #pragma unroll
-  for (int o = LPR >> 1; o > 0; o >>= 1) acc += __shfl_down(acc, o, LPR);
-  if (row < nrows && sub == 0) y[row] = acc;
+        for (int u = 0; u < 4; ++u) {
+          const int q = min(i + u * 256, n - 1);
+          v[u] = values[p0 + q];
+          c[u] = colind[p0 + q];
+        }
+        V xx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) xx[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (i + u * 256 < n) prod[i + u * 256] = v[u] * xx[u];
+      }
+      __syncthreads();
+      // 4 lanes per row, rows strided over the workgroup
+      const int sub = tid & 3;
+      for (int r = r0 + (tid >> 2); r < r1; r += 64) {
+        const int b0 = rowptr[r] - p0, e0 = rowptr[r + 1] - p0;
+        V acc = V(0);
+        for (int j = b0 + sub; j < e0; j += 4) acc += prod[j];
+        acc += __shfl_down(acc, 2, 4);
+        acc += __shfl_down(acc, 1, 4);
+        if (sub == 0) y[r] = acc;
+      }
+      __syncthreads();
+    } else { // one long row (r1 == r0 + 1 by construction)
+      V acc = V(0);
+      for (int j = p0 + tid; j < p1; j += 256) acc = fma(values[j], x[colind[j]], acc);
+      part[tid] = acc;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) part[tid] += part[tid + o];
+        __syncthreads();
+      }
+      if (tid == 0) y[r0] = part[0];
+      __syncthreads();
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -689,9 +735,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
 };
 
 struct cfs_hip_csr_s {
-  int value_bytes = 8, nrows = 0, ncols = 0, lpr = 16;
+  int value_bytes = 8, nrows = 0, ncols = 0, nblocks = 0;
   int64_t nnz = 0;
-  DevBuf rowptr, colind, values, xstage, ystage;
+  DevBuf rowptr, colind, values, blk_row, xstage, ystage;
 };
 
 // ---------------------------------------------------------------------------
@@ -1124,8 +1170,22 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     delete m;
     return rc;
   }
-  double avg = nrows ? (double)m->nnz / nrows : 0;
-  m->lpr = avg > 48 ? 64 : avg > 24 ? 32 : avg > 12 ? 16 : avg > 6 ? 8 : 4;
+  { // row blocks of at most kCsrNnz nonzeros (a longer row is a block by itself)
+    std::vector<int32_t> blk(1, 0);
+    int r = 0;
+    while (r < nrows) {
+      int e = r;
+      while (e < nrows && rowptr[e + 1] - rowptr[r] <= kCsrNnz && e - r < 4096) e++;
+      if (e == r) e = r + 1;
+      blk.push_back(e);
+      r = e;
+    }
+    m->nblocks = (int)blk.size() - 1;
+    if ((rc = m->blk_row.upload(blk.data(), blk.size() * 4))) {
+      delete m;
+      return rc;
+    }
+  }
   *out = m;
   return 0;
 }
@@ -1138,30 +1198,22 @@ int cfs_hip_csr_create_f32(int nrows, int ncols, const int *rowptr, const int *c
   return csr_create<float>(nrows, ncols, rowptr, colind, values, out);
 }
 
-template <typename V, int LPR>
-static void csr_launch(cfs_hip_csr_t h, V *y, const V *x, hipStream_t st) {
-  long threads = (long)h->nrows * LPR;
-  int blocks = (int)((threads + 255) / 256);
-  if (blocks == 0) return;
-  hipLaunchKernelGGL((cfs_csr_kernel<V, LPR>), dim3(blocks), dim3(256), 0, st, h->nrows,
-                     (const int32_t *)h->rowptr.p, (const int32_t *)h->colind.p,
-                     (const V *)h->values.p, x, y);
-}
-template <typename V> static void csr_dispatch(cfs_hip_csr_t h, V *y, const V *x, hipStream_t st) {
-  switch (h->lpr) {
-  case 64: csr_launch<V, 64>(h, y, x, st); break;
-  case 32: csr_launch<V, 32>(h, y, x, st); break;
-  case 16: csr_launch<V, 16>(h, y, x, st); break;
-  case 8: csr_launch<V, 8>(h, y, x, st); break;
-  default: csr_launch<V, 4>(h, y, x, st); break;
-  }
-}
-
 int cfs_hip_csr_spmv_async(cfs_hip_csr_t h, void *y, const void *x, void *stream) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
-  if (h->value_bytes == 8) csr_dispatch<double>(h, (double *)y, (const double *)x, st);
-  else csr_dispatch<float>(h, (float *)y, (const float *)x, st);
+  if (h->nblocks > 0) {
+    const int grid = h->nblocks < 256 * 8 ? h->nblocks : 256 * 8;
+    if (h->value_bytes == 8)
+      hipLaunchKernelGGL((cfs_csr_stream_kernel<double>), dim3(grid), dim3(256), 0, st,
+                         (const int32_t *)h->blk_row.p, h->nblocks, (const int32_t *)h->rowptr.p,
+                         (const int32_t *)h->colind.p, (const double *)h->values.p,
+                         (const double *)x, (double *)y);
+    else
+      hipLaunchKernelGGL((cfs_csr_stream_kernel<float>), dim3(grid), dim3(256), 0, st,
+                         (const int32_t *)h->blk_row.p, h->nblocks, (const int32_t *)h->rowptr.p,
+                         (const int32_t *)h->colind.p, (const float *)h->values.p,
+                         (const float *)x, (float *)y);
+  }
   HIPCHK(hipGetLastError());
   return 0;
 }

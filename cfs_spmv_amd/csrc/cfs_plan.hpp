@@ -33,6 +33,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -122,6 +123,17 @@ template <typename V> struct SymPlan {
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// a persistent group should own at least this many rows (experiments:
+// CFS_PLAN_MIN_ROWS overrides)
+inline int min_rows_per_group() {
+  static int v = [] {
+    const char *e = getenv("CFS_PLAN_MIN_ROWS");
+    int r = e ? atoi(e) : 64;
+    return r < 16 ? 16 : r;
+  }();
+  return v;
+}
 
 // Position of entry (lane l, diagonal j of the packet) inside a packet that
 // covers `cnt` lanes (4*cnt entries).  Values: two fully contiguous
@@ -230,7 +242,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     if (wg_per_cu < 1) wg_per_cu = 1;
     const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
     int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
-    int by_rows = ((rows + 63) / 64 + 7) / 8 * 8;
+    int by_rows = ((rows + min_rows_per_group() - 1) / min_rows_per_group() + 7) / 8 * 8;
     if (ngroups > by_rows) ngroups = by_rows;
     if (ngroups < 8) ngroups = 8;
     P.ngroups = ngroups;
@@ -735,7 +747,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   if (wg_per_cu < 1) wg_per_cu = 1;
   const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
   int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
-  int by_rows = ((rows + 63) / 64 + 7) / 8 * 8;
+  int by_rows = ((rows + min_rows_per_group() - 1) / min_rows_per_group() + 7) / 8 * 8;
   if (ngroups > by_rows) ngroups = by_rows;
   if (ngroups < 8) ngroups = 8;
 
@@ -798,15 +810,17 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
                           opt, &chunk, &perm, P))
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
                               nullptr, nullptr, P); // e.g. a cluster row too dense: natural order
-  // keep the clustered schedule only if it really has fewer halo slots (random
-  // sparsity has no locality to find; banded matrices are already compact)
+  // keep the clustered schedule only if it has at least 2.5x fewer halo slots:
+  // clustered tiles pay for their compactness with scattered x / y accesses
+  // (measured on MI355X: Flan stand-in 3.3x fewer halo slots -> 5 % faster; pwtk
+  // stand-in 2.1x fewer -> 11 % slower; random sparsity has no locality to find)
   if (opt.force_order != 2) {
     std::vector<int32_t>().swap(bci);
     std::vector<V>().swap(bva);
     SymPlan<V> N;
     if (build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
                            nullptr, N) &&
-        N.nhalo + (int64_t)N.tiles.size() * 64 <= P.nhalo + (int64_t)P.tiles.size() * 64)
+        2 * N.nhalo <= 5 * P.nhalo)
       P = std::move(N);
   }
   return true;

@@ -21,26 +21,30 @@ class ShardedSym:
     spmv_local(y_block, x, send), recv_fold(y_block, recv), row_begin, row_end.
     On a GPU box that is cfs_spmv_amd.SymMatrix; CPU tests pass a double."""
 
-    def __init__(self, backend, nranks, rank, dtype, device, pg=None):
+    def __init__(self, backend, nranks, rank, dtype, device, pg=None, stage_via_host=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
         self.A, self.nranks, self.rank, self.pg = backend, nranks, rank, pg
         self.device = device
+        # rehearsal mode (several ranks on ONE GPU over gloo): collectives run on
+        # host copies of the device buffers.  Never used with the nccl backend.
+        self.stage = bool(stage_via_host)
+        cdev = torch.device("cpu") if self.stage else device
         tdt = torch.float64 if np.dtype(dtype) == np.float64 else torch.float32
         send_counts = np.asarray(backend.send_counts(), dtype=np.int64)
         send_rows = np.asarray(backend.send_rows(), dtype=np.int32)
         assert send_counts.sum() == send_rows.size
         # 1) counts
-        sc = torch.from_numpy(send_counts).to(device)
-        rc = torch.zeros(nranks, dtype=torch.int64, device=device)
+        sc = torch.from_numpy(send_counts).to(cdev)
+        rc = torch.zeros(nranks, dtype=torch.int64, device=cdev)
         dist.all_to_all_single(rc, sc, group=pg)
         self.send_splits = [int(v) for v in send_counts]
         self.recv_splits = [int(v) for v in rc.cpu().numpy()]
         # 2) row lists (static): what will arrive where
         nrecv = sum(self.recv_splits)
-        sr = torch.from_numpy(send_rows.astype(np.int32)).to(device)
-        rr = torch.zeros(nrecv, dtype=torch.int32, device=device)
+        sr = torch.from_numpy(send_rows.astype(np.int32)).to(cdev)
+        rr = torch.zeros(nrecv, dtype=torch.int32, device=cdev)
         dist.all_to_all_single(rr, sr, self.recv_splits, self.send_splits, group=pg)
         backend.set_recv(rr.cpu().numpy())
         self.send_buf = torch.zeros(max(1, send_rows.size), dtype=tdt, device=device)
@@ -54,6 +58,12 @@ class ShardedSym:
 
     def exchange_and_fold(self, y_block):
         """the one collective of the path + the owner-side sum (fixed order)"""
-        self.dist.all_to_all_single(self.recv_buf[:self.nrecv], self.send_buf[:self.nsend],
-                                    self.recv_splits, self.send_splits, group=self.pg)
+        if self.stage:
+            sh = self.send_buf[:self.nsend].cpu()
+            rh = self.torch.zeros(self.nrecv, dtype=sh.dtype)
+            self.dist.all_to_all_single(rh, sh, self.recv_splits, self.send_splits, group=self.pg)
+            self.recv_buf[:self.nrecv].copy_(rh)
+        else:
+            self.dist.all_to_all_single(self.recv_buf[:self.nrecv], self.send_buf[:self.nsend],
+                                        self.recv_splits, self.send_splits, group=self.pg)
         self.A.recv_fold(y_block, self.recv_buf)

@@ -196,3 +196,47 @@ def test_shards_on_one_device(nranks, dtype):
     assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
     for s in shards:
         s.close()
+
+
+@pytest.mark.parametrize("flags", [0, 8])
+def test_long_rows_are_split_over_lanes(flags):
+    """a few rows 30x longer than the rest: virtual rows (chunks of one row on
+    several lanes, partial sums meeting in one LDS slot), many slices per wave
+    (ticket scheduling), both row orders"""
+    import scipy.sparse as sp
+    import cfs_spmv_amd as cfs
+    n = 6000
+    rng = np.random.default_rng(11)
+    rows, cols = [], []
+    for i in range(1, n):
+        k = 600 if (i % 997 == 0) else 12
+        c = np.unique(rng.integers(max(0, i - 1500), i, size=min(k, i)))
+        rows.append(np.full(c.size, i))
+        cols.append(c)
+    r, c = np.concatenate(rows), np.concatenate(cols)
+    L = sp.coo_matrix((rng.uniform(-1, 1, r.size), (r, c)), shape=(n, n)).tocsr()
+    A = (L + L.T + sp.diags(rng.uniform(1, 2, n))).tocsr()
+    A.sort_indices()
+    x = rng.uniform(-1, 1, n)
+    for dtype in (np.float64, np.float32):
+        _check(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data, x, dtype,
+               options=cfs.make_options(max_slots=2496, flags=flags), threads=(1, 3))
+
+
+def test_natural_and_clustered_orders_agree():
+    """CFS_HIP_FLAG_NO_REORDER vs the default on a matrix where clustering is
+    chosen (3-D stencil): same y up to summation order"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from oracle import oracle
+    torch = _torch()
+    n, rp, ci, va, _ = synth.generate("Flan_1565", 0.05)
+    x = synth.make_x(n)
+    ys = []
+    for flags in (0, 8):
+        A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=flags))
+        ys.append(_gpu_spmv(A, x, torch))
+        A.close()
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(ys[0], y_ld, absrow) <= 1e-12 and scaled_err(ys[1], y_ld, absrow) <= 1e-12
+    assert scaled_err(ys[0], ys[1], absrow) <= 1e-13

@@ -17,6 +17,20 @@ if f32:
     va = va.astype(np.float32)
 x = torch.from_numpy(synth.make_x(n, 42, np.float32 if f32 else np.float64)).cuda()
 y = torch.empty(n, dtype=x.dtype, device="cuda")
+if os.environ.get("QB_CSR"):
+    G = cfs.CsrMatrix(n, n, rp, ci, va)
+    for _ in range(3):
+        G.dense_vector_multiply(y, x)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        G.dense_vector_multiply(y, x)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 20
+    b = int(rp[-1]) * (4 + va.itemsize) + n * (4 + 2 * va.itemsize)
+    print(json.dumps(dict(cfg="csr", ms=round(ms, 4), GBs=round(b / ms / 1e6, 1), frac=round(b / ms / 1e6 / 8000, 3))), flush=True)
+    G.close()
 for cfg in configs:
     slots, block = (int(v) for v in cfg.split(",")[:2])
     mtn = int(cfg.split(",")[2]) if cfg.count(",") >= 2 else 0
