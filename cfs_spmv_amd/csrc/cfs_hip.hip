@@ -842,7 +842,7 @@ template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
   return 0;
 }
 template <typename V> static int query_residency(cfs_plan::Options &po) {
-  int block = po.block_threads > 0 ? po.block_threads : 256;
+  int block = po.block_threads > 0 ? po.block_threads : cfs_plan::kDefaultBlock;
   int slots = po.max_slots > 0 ? po.max_slots : cfs_plan::kDefaultSlots;
   const int slot_bytes = (int)sizeof(V) + 8;
   if (slots > (160 * 1024 - 64) / slot_bytes) slots = (160 * 1024 - 64) / slot_bytes;

@@ -83,7 +83,8 @@ struct SliceMeta {
 constexpr int kLanes = 64;
 constexpr int kPacket = 4;            // diagonals per packet
 constexpr int kAlignEntries = 8;      // slice streams start on 8-entry bounds
-constexpr int kDefaultSlots = 2496;    // 4 workgroups x (2496 x 16 B + 16 B) fit the 160 KiB of a CU
+constexpr int kDefaultSlots = 4992;    // 2 workgroups x (4992 x 16 B + 16 B) fit the 160 KiB of a CU
+constexpr int kDefaultBlock = 512;    // 8 waves per workgroup, 16 per CU (measured best)
 constexpr int kStaticLds = 16;        // slice ticket counter
 constexpr int kSlotsPerThread = 10;   // LDS slots one thread fills/flushes (registers)
 
@@ -198,7 +199,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   if (max_slots > 65536) max_slots = 65536;
   if (max_slots < 64) max_slots = 64;
   P.max_slots = max_slots;
-  int block = opt.block_threads > 0 ? opt.block_threads : 256;
+  int block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
   if (block != 256 && block != 512 && block != 1024) {
     P.error = "block_threads must be 256, 512 or 1024";
     return false;
@@ -736,7 +737,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
                               nullptr, nullptr, P);
   // number of persistent groups: same rule as the core
-  int block = opt.block_threads > 0 ? opt.block_threads : 256;
+  int block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
   int max_slots = opt.max_slots > 0 ? opt.max_slots : kDefaultSlots;
   const int slot_bytes = (int)sizeof(V) + 8;
   max_slots = std::min(max_slots, std::min((160 * 1024 - 64) / slot_bytes, kSlotsPerThread * block));
@@ -812,15 +813,17 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
                               nullptr, nullptr, P); // e.g. a cluster row too dense: natural order
   // keep the clustered schedule only if it has at least 2.5x fewer halo slots:
   // clustered tiles pay for their compactness with scattered x / y accesses
-  // (measured on MI355X: Flan stand-in 3.3x fewer halo slots -> 5 % faster; pwtk
-  // stand-in 2.1x fewer -> 11 % slower; random sparsity has no locality to find)
+  // (measured on MI355X, fp64: Flan stand-in 3.5x fewer halo slots -> 8 % faster;
+  // pwtk stand-in 2.1x fewer -> 11 % slower; random sparsity has no locality to
+  // find).  In fp32 the scattered 4-byte accesses weigh twice as much against a
+  // stream half as long: the same 3.5x is 7 % slower, so the bar is 6x there.
   if (opt.force_order != 2) {
     std::vector<int32_t>().swap(bci);
     std::vector<V>().swap(bva);
     SymPlan<V> N;
     if (build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
                            nullptr, N) &&
-        2 * N.nhalo <= 5 * P.nhalo)
+        (sizeof(V) == 8 ? 2 * N.nhalo <= 5 * P.nhalo : N.nhalo <= 6 * P.nhalo))
       P = std::move(N);
   }
   return true;
