@@ -55,7 +55,7 @@ template <typename V> struct SymDev {
   const int32_t *slot_col; // original column of every slot of every tile
   const uint32_t *rowinfo;
   const V *diag;
-  const uint2 *slice_meta; // {entry offset inside the tile, lanes of packet 0}
+  const uint4 *slice_meta; // {value offset, slot offset | lanes of packet 0 << 25, leader mask}
   const V *vals;
   const uint16_t *slots;
   const V *cvals; // COO leftovers (len % 4 per row): value, row slot, column slot
@@ -76,22 +76,33 @@ template <typename V> struct Pkt {
   ushort4 c;
 };
 
+// `leaders` (one bit per lane of the slice): lanes whose whole slot sequence
+// repeats the lane before them store no slots; every lane reads the slots of
+// the last leader at or below it (rank among the leaders = position in the
+// packet's slot block).
+__device__ __forceinline__ int leader_rank(unsigned long long leaders, int l) {
+  return __popcll(leaders & (~0ull >> (63 - l))) - 1;
+}
 __device__ __forceinline__ void fetch_packet(Pkt<double> &p, const double *tv,
-                                             const uint16_t *ts, uint32_t off, int cnt,
-                                             int lane) {
+                                             const uint16_t *ts, uint32_t off, uint32_t soff,
+                                             int cnt, unsigned long long leaders, int lane) {
   const int ll = min(lane, max(cnt, 1) - 1);
   const double2 lo = *reinterpret_cast<const double2 *>(tv + off + ll * 2);
   const double2 hi = *reinterpret_cast<const double2 *>(tv + off + 2 * cnt + ll * 2);
-  p.c = *reinterpret_cast<const ushort4 *>(ts + off + ll * 4);
+  p.c = *reinterpret_cast<const ushort4 *>(ts + soff + leader_rank(leaders, ll) * 4);
   p.v[0] = lo.x; p.v[1] = lo.y; p.v[2] = hi.x; p.v[3] = hi.y;
 }
 __device__ __forceinline__ void fetch_packet(Pkt<float> &p, const float *tv,
-                                             const uint16_t *ts, uint32_t off, int cnt,
-                                             int lane) {
+                                             const uint16_t *ts, uint32_t off, uint32_t soff,
+                                             int cnt, unsigned long long leaders, int lane) {
   const int ll = min(lane, max(cnt, 1) - 1);
   const float4 q = *reinterpret_cast<const float4 *>(tv + off + ll * 4);
-  p.c = *reinterpret_cast<const ushort4 *>(ts + off + ll * 4);
+  p.c = *reinterpret_cast<const ushort4 *>(ts + soff + leader_rank(leaders, ll) * 4);
   p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
+}
+// entries of the packet's slot block = 4 x (leaders among its cnt lanes)
+__device__ __forceinline__ uint32_t slot_block(unsigned long long leaders, int cnt) {
+  return cnt > 0 ? 4u * (uint32_t)__popcll(leaders & (~0ull >> (64 - cnt))) : 0u;
 }
 
 // one stored nonzero a = A[row][col(c)]: row side into the register
@@ -150,11 +161,11 @@ __global__ void __launch_bounds__(BLOCK)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const int32_t *__restrict__ a_group_ptr,
                         const int32_t *__restrict__ a_slot_col,
                         const uint32_t *__restrict__ a_rowinfo, const V *__restrict__ a_diag,
-                        const uint2 *__restrict__ a_slice_meta, const V *__restrict__ a_vals,
+                        const uint4 *__restrict__ a_slice_meta, const V *__restrict__ a_vals,
                         const uint16_t *__restrict__ a_slots, const V *__restrict__ a_cvals,
                         const uint16_t *__restrict__ a_crows,
                         const uint16_t *__restrict__ a_ccols, V *__restrict__ a_strip,
-                        const int a_row_begin, const int a_lds_slots,
+                        const int a_row_begin, const int a_lds_slots, const int xcd_shift,
                         const V *__restrict__ x, V *__restrict__ y,
                         unsigned long long *__restrict__ dbg) {
   // every array is a separate __restrict__ argument: read-only metadata at
@@ -166,7 +177,7 @@ __global__ void __launch_bounds__(BLOCK)
     const int32_t *__restrict__ slot_col;
     const uint32_t *__restrict__ rowinfo;
     const V *__restrict__ diag;
-    const uint2 *__restrict__ slice_meta;
+    const uint4 *__restrict__ slice_meta;
     const V *__restrict__ vals;
     const uint16_t *__restrict__ slots;
     const V *__restrict__ cvals;
@@ -191,7 +202,7 @@ __global__ void __launch_bounds__(BLOCK)
   // contiguous run of groups so neighbouring tiles share halo lines in one L2.
   // Placement only affects speed, never correctness.
   const int nper = gridDim.x >> 3;
-  const int g = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
+  const int g = (((int)blockIdx.x + xcd_shift) & 7) * nper + (blockIdx.x >> 3);
   const int t0 = d.group_ptr[g], t1 = d.group_ptr[g + 1];
   // developer timeline (cfs_hip_sym_debug_timeline): 100 MHz wall clock stamps of
   // this workgroup's phases; dbg is NULL in every product launch
@@ -231,8 +242,8 @@ __global__ void __launch_bounds__(BLOCK)
     const int nown = t.nown, nslots = t.nslots;
     const int vrow0 = t.vrow_off, nvr = t.nvrows;
     const V *tv = d.vals + t.nnz_off;
-    const uint16_t *ts = d.slots + t.nnz_off;
-    const uint2 *smeta = d.slice_meta + t.slice_base;
+    const uint16_t *ts = d.slots + t.sl_off;
+    const uint4 *smeta = d.slice_meta + t.slice_base;
     const int nsl = t.nslices;
 
     // the matrix stream does not depend on x: request this wave's first slice
@@ -242,7 +253,7 @@ __global__ void __launch_bounds__(BLOCK)
     // slices `wave` and `wave + NW` and draws every later one from an LDS
     // ticket counter one slice ahead of its use.
     int s = wave, s_n = wave + NW;
-    uint2 meta_c = make_uint2(0u, 0u), meta_n = make_uint2(0u, 0u);
+    uint4 meta_c = make_uint4(0u, 0u, 0u, 0u), meta_n = meta_c;
     uint32_t info_c = 0u;
     V dg_c = V(0);
     Pkt<V> N;
@@ -256,7 +267,8 @@ __global__ void __launch_bounds__(BLOCK)
       const V d0 = d.diag[vrow0 + q0];
       info_c = p0 < nvr ? i0 : 0u;
       dg_c = p0 < nvr ? d0 : V(0);
-      fetch_packet(N, tv, ts, meta_c.x, (int)meta_c.y, lane);
+      fetch_packet(N, tv, ts, meta_c.x, meta_c.y & 0x1ffffffu, (int)(meta_c.y >> 25),
+                   ((unsigned long long)meta_c.w << 32) | meta_c.z, lane);
     }
     const int ncp = (t.ncoo + 255) >> 8; // COO packets of this tile
     Pkt<V> C;
@@ -264,7 +276,8 @@ __global__ void __launch_bounds__(BLOCK)
     C.v[0] = C.v[1] = C.v[2] = C.v[3] = V(0);
     C.c = Cr;
     if (wave < ncp) {
-      fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)wave * 256u, 64, lane);
+      fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)wave * 256u,
+                   (uint32_t)wave * 256u, 64, ~0ull, lane);
       Cr = *reinterpret_cast<const ushort4 *>(d.crows + t.coo_off + wave * 256 + lane * 4);
     }
     // flush the previous tile's y window and refill both windows.  A thread
@@ -292,8 +305,9 @@ __global__ void __launch_bounds__(BLOCK)
     while (MODE != 3 && s < nsl) {
       const uint32_t info = info_c;
       const V dg = dg_c;
-      uint32_t off = meta_c.x;
-      int cnt = (int)meta_c.y;
+      uint32_t off = meta_c.x, soff = meta_c.y & 0x1ffffffu;
+      int cnt = (int)(meta_c.y >> 25);
+      const unsigned long long leaders = ((unsigned long long)meta_c.w << 32) | meta_c.z;
       Pkt<V> A = N;
       // ticket for the slice after next (its metadata is a scalar load that
       // lands long before it is needed)
@@ -307,7 +321,8 @@ __global__ void __launch_bounds__(BLOCK)
         const V dn = d.diag[vrow0 + qn];
         info_c = pn < nvr ? in_ : 0u;
         dg_c = pn < nvr ? dn : V(0);
-        fetch_packet(N, tv, ts, meta_n.x, (int)meta_n.y, lane);
+        fetch_packet(N, tv, ts, meta_n.x, meta_n.y & 0x1ffffffu, (int)(meta_n.y >> 25),
+                     ((unsigned long long)meta_n.w << 32) | meta_n.z, lane);
       }
       meta_c = meta_n;
       if (s_nn < nsl) meta_n = smeta[s_nn];
@@ -325,20 +340,22 @@ __global__ void __launch_bounds__(BLOCK)
       Pkt<V> B;
       while (g + 2 < amax) { // steady state: two packets per trip, no copies
         const int cnt1 = __popcll(__ballot(a > g + 1));
-        const uint32_t off1 = off + 4u * (uint32_t)cnt;
-        fetch_packet(B, tv, ts, off1, cnt1, lane);
+        const uint32_t off1 = off + 4u * (uint32_t)cnt, soff1 = soff + slot_block(leaders, cnt);
+        fetch_packet(B, tv, ts, off1, soff1, cnt1, leaders, lane);
         if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
         const int cnt2 = __popcll(__ballot(a > g + 2));
-        const uint32_t off2 = off1 + 4u * (uint32_t)cnt1;
-        fetch_packet(A, tv, ts, off2, cnt2, lane);
+        const uint32_t off2 = off1 + 4u * (uint32_t)cnt1, soff2 = soff1 + slot_block(leaders, cnt1);
+        fetch_packet(A, tv, ts, off2, soff2, cnt2, leaders, lane);
         if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
         g += 2;
         off = off2;
+        soff = soff2;
         cnt = cnt2;
       }
       if (amax - g == 2) {
         const int cnt1 = __popcll(__ballot(a > g + 1));
-        fetch_packet(B, tv, ts, off + 4u * (uint32_t)cnt, cnt1, lane);
+        fetch_packet(B, tv, ts, off + 4u * (uint32_t)cnt, soff + slot_block(leaders, cnt), cnt1,
+                     leaders, lane);
         if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
         if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
       } else if (amax - g == 1) {
@@ -352,7 +369,8 @@ __global__ void __launch_bounds__(BLOCK)
       const Pkt<V> Q = C;
       const ushort4 Qr = Cr;
       if (cp + NW < ncp) {
-        fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)(cp + NW) * 256u, 64, lane);
+        fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)(cp + NW) * 256u,
+                     (uint32_t)(cp + NW) * 256u, 64, ~0ull, lane);
         Cr = *reinterpret_cast<const ushort4 *>(d.crows + t.coo_off + (cp + NW) * 256 + lane * 4);
       }
       const int e0 = cp * 256 + lane * 4;
@@ -522,8 +540,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int nfold = 0, nsend = 0, nrfold = 0;
   int ablate_mode = 0; // cfs_hip_options.flags & 7 (timing-only ablations)
   unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
+  int xcd_shift = getenv("CFS_XCD_SHIFT") ? atoi(getenv("CFS_XCD_SHIFT")) : 0; // experiment knob
   size_t lds_bytes = 0;
-  int64_t halo_slots = 0, stream_len = 0, nslices = 0, coo_len = 0;
+  int64_t halo_slots = 0, stream_len = 0, slot_len = 0, nslices = 0, coo_len = 0;
 
   int upload() {
     int rc;
@@ -549,6 +568,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     if ((rc = strip.alloc((size_t)P.nhalo * sizeof(V)))) return rc;
     halo_slots = P.nhalo;
     stream_len = P.stream_len;
+    slot_len = P.slot_len;
     nslices = (int64_t)P.slice_meta.size();
     coo_len = P.coo_len;
     nfold = (int)P.fold_dst.size();
@@ -558,7 +578,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     dev.slot_col = (const int32_t *)slot_col.p;
     dev.rowinfo = (const uint32_t *)rowinfo.p;
     dev.diag = (const V *)diag.p;
-    dev.slice_meta = (const uint2 *)slice_meta.p;
+    dev.slice_meta = (const uint4 *)slice_meta.p;
     dev.cvals = (const V *)cvals.p;
     dev.crows = (const uint16_t *)crows.p;
     dev.ccols = (const uint16_t *)ccols.p;
@@ -608,27 +628,27 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 1>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
     else if (mode == 2)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 2>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
     else if (mode == 3)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 3>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
     else if (mode == 4)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 4>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
     else
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 0>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
   }
 
   int spmv_local(void *yv, const void *xv, void *sendv, hipStream_t st, int phases) override {
@@ -701,10 +721,10 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     o->remote_vals = nsend;
     o->lds_bytes = (int64_t)lds_bytes;
     o->bytes_algorithmic = P.nnz_low * (4 + s) + rows_ * (4 + 3 * s);
-    o->bytes_streamed = stream_len * (s + 2) + coo_len * (s + 4) + rows_ * (4 + 3 * s) +
+    o->bytes_streamed = stream_len * s + slot_len * 2 + coo_len * (s + 4) + rows_ * (4 + 3 * s) +
                         halo_slots * (4 + 2 * s) + rows_ * 8 /* slot_col, x, strip st */
                         + halo_slots * (4 + s)              /* fold: idx + strip ld  */
-                        + (int64_t)(nfold + nsend) * (8 + 2 * s) + nslices * 8 +
+                        + (int64_t)(nfold + nsend) * (8 + 2 * s) + nslices * 16 +
                         (int64_t)P.tiles.size() * (int64_t)sizeof(Tile);
     o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + slot_col.bytes +
                                 rowinfo.bytes + diag.bytes + slice_meta.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +

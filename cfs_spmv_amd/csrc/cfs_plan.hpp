@@ -32,7 +32,9 @@
 #pragma once
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -65,20 +67,23 @@ struct Tile {
   int32_t nslices;    // ceil(nvrows / 64)
   int32_t halo_off;   // offset of this tile's halo in halo_col[] and strip[]
   int32_t slice_base; // offset of this tile's slices in slice_meta[]
-  int64_t nnz_off;    // offset of this tile's packet stream in vals[] / slots[]
+  int64_t nnz_off;    // offset of this tile's value stream in vals[]
+  int64_t sl_off;     // offset of this tile's slot stream in slots[]
   int32_t coo_off;    // offset of this tile's COO section in cvals/crows/ccols
   int32_t ncoo;       // leftover entries (len % 4 per row)
   int32_t slot_off;   // offset of this tile's slots in slot_col[]
   int32_t vrow_off;   // offset of this tile's virtual rows in rowinfo[] / diag[]
   int32_t nvrows;     // virtual rows (>= nown: long rows are split over lanes)
-  int32_t pad_[3];
+  int32_t pad_;
 };
 static_assert(sizeof(Tile) == 64, "Tile must stay 64 bytes");
 
 struct SliceMeta {
-  uint32_t off;  // entry offset of the slice's first packet inside its tile
-  uint32_t cnt0; // lanes of that first packet (rows of the slice with >= 4 entries)
+  uint32_t voff;      // entry offset of the slice's first packet in the tile's value stream
+  uint32_t soff_cnt0; // bits 0..24: offset in the tile's slot stream; bits 25..31: lanes of packet 0
+  uint64_t leaders;   // bit l = lane l stores its own slots; 0 = it repeats lane l-1's
 };
+static_assert(sizeof(SliceMeta) == 16, "SliceMeta must stay 16 bytes");
 
 constexpr int kLanes = 64;
 constexpr int kPacket = 4;            // diagonals per packet
@@ -107,7 +112,8 @@ template <typename V> struct SymPlan {
   int64_t nvrows = 0;
   std::vector<SliceMeta> slice_meta; // [S]
   std::vector<V> vals;              // [stream_len + pad] packet stream
-  std::vector<uint16_t> slots;      // [stream_len + pad]
+  std::vector<uint16_t> slots;      // [slot_len + pad]: only the leader lanes' slots
+  int64_t slot_len = 0;
   std::vector<V> cvals;             // [coo_len] COO leftovers, packet layout
   std::vector<uint16_t> crows, ccols; // [coo_len]
   int64_t coo_len = 0, coo_entries = 0;
@@ -124,6 +130,19 @@ template <typename V> struct SymPlan {
 };
 
 inline int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+// CFS_PLAN_VERBOSE=1 prints where tune() spends its host time
+struct PhaseTimer {
+  bool on;
+  std::chrono::steady_clock::time_point t;
+  PhaseTimer() : on(getenv("CFS_PLAN_VERBOSE") != nullptr), t(std::chrono::steady_clock::now()) {}
+  void lap(const char *what) {
+    if (!on) return;
+    auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[cfs_plan] %-28s %8.3f s\n", what, std::chrono::duration<double>(n - t).count());
+    t = n;
+  }
+};
 
 // a persistent group should own at least this many rows (experiments:
 // CFS_PLAN_MIN_ROWS overrides)
@@ -226,6 +245,8 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   P.nnz_low = nnz_low;
   P.nnz_diag = nnz_diag;
   P.nnz_full = 2 * nnz_low + nnz_diag;
+  PhaseTimer pt;
+  pt.lap("core: lower counts");
 
   // ---- persistent groups first, tiles inside them ----------------------------
   // A CU only streams ~1/256 of the HBM bandwidth, so the launch is as long as
@@ -340,6 +361,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     P.group_ptr[ngroups] = (int32_t)P.tiles.size();
   }
   const int T = (int)P.tiles.size();
+  pt.lap("core: cut tiles");
 
   // ---- virtual rows: one lane each ----------------------------------------------
   // A lane normally owns a whole row.  A row much longer than its neighbours
@@ -418,40 +440,86 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     P.nhalo = halo;
     P.halo_col.assign((size_t)halo + 1, 0);
     P.slot_col.assign((size_t)nsl + 1, 0); // +1: the kernel's clamped dummy read
-    P.slice_meta.assign((size_t)slices, SliceMeta{0u, 0u});
+    P.slice_meta.assign((size_t)slices, SliceMeta{0u, 0u, 0ull});
     P.rowinfo.assign((size_t)nvr + 1, 0);
     P.diag.assign((size_t)nvr + 1, V(0));
     P.nvrows = nvr;
   }
 
   // ---- per tile: stream sizes, then fill ------------------------------------------
+  // Multi-dof FEM matrices repeat themselves: the rows of one mesh node have
+  // (nearly) the same columns.  A lane whose whole packet-covered column
+  // sequence equals that of the lane before it (same packet count) does not
+  // store slots at all: it reads the slots of the last LEADER lane at or below
+  // it (same address -> one cache line serves the run).  One 64-bit leader
+  // mask per slice.  (Flan stand-in: 42 % of the slot stream disappears,
+  // ldoor: 61 %.)
+  std::vector<int64_t> tile_slen(T, 0);
+  auto lower_cols = [&](int i, int k0, int cnt, std::vector<int32_t> &out) {
+    out.clear();
+    int seen = 0;
+    for (int j = rowptr[i]; j < rowptr[i + 1] && (int)out.size() < cnt; j++)
+      if (colind[j] < i) {
+        if (seen >= k0) out.push_back(colind[j]);
+        seen++;
+      }
+  };
 #pragma omp parallel
   {
     std::vector<VRow> vr;
+    std::vector<int32_t> prev, cur;
 #pragma omp for schedule(dynamic, 8)
     for (int ti = 0; ti < T; ti++) {
       Tile &t = P.tiles[ti];
       build_vrows(t, vr);
-      int64_t off = 0;
+      int64_t off = 0, soff = 0;
       for (int s = 0; s < t.nslices; s++) {
         off = align_up(off, kAlignEntries);
+        soff = align_up(soff, 4);
         int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nvrows);
         uint32_t cnt0 = 0;
-        P.slice_meta[t.slice_base + s].off = (uint32_t)off;
+        uint64_t leaders = 0;
+        SliceMeta &sm = P.slice_meta[t.slice_base + s];
+        sm.voff = (uint32_t)off;
+        if (soff >= (1 << 25)) tile_slen[ti] = -1; // flagged below
+        sm.soff_cnt0 = (uint32_t)soff;
+        prev.clear();
         for (int p = p0; p < p1; p++) {
-          off += (int64_t)vr[p].a * 4;
-          if (vr[p].a >= 1) cnt0++;
+          const VRow &v = vr[p];
+          off += (int64_t)v.a * 4;
+          if (v.a >= 1) cnt0++;
+          bool leader = true;
+          if (v.a >= 1) {
+            lower_cols(t.row0 + v.r, v.k0 * 4, v.a * 4, cur);
+            if (p > p0 && vr[p - 1].a == v.a && cur == prev) leader = false;
+            prev.swap(cur);
+          } else {
+            prev.clear();
+          }
+          if (leader) {
+            leaders |= 1ull << (p - p0);
+            soff += (int64_t)v.a * 4;
+          }
         }
-        P.slice_meta[t.slice_base + s].cnt0 = cnt0;
+        for (int l = p1 - p0; l < kLanes; l++) leaders |= 1ull << l; // unused lanes: own (empty) runs
+        sm.soff_cnt0 |= cnt0 << 25;
+        sm.leaders = leaders;
       }
       tile_len[ti] = align_up(off, kAlignEntries);
+      if (tile_slen[ti] >= 0) tile_slen[ti] = align_up(soff, kAlignEntries);
     }
   }
   {
-    int64_t off = 0, coo = 0;
+    int64_t off = 0, soff = 0, coo = 0;
     for (int ti = 0; ti < T; ti++) {
+      if (tile_slen[ti] < 0) {
+        P.error = "tile slot stream exceeds 2^25 entries";
+        return false;
+      }
       P.tiles[ti].nnz_off = off;
       off += tile_len[ti];
+      P.tiles[ti].sl_off = soff;
+      soff += tile_slen[ti];
       P.tiles[ti].coo_off = (int32_t)coo;
       P.coo_entries += P.tiles[ti].ncoo;
       coo += align_up(P.tiles[ti].ncoo, 256);
@@ -461,15 +529,17 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
       }
     }
     P.stream_len = off;
+    P.slot_len = soff;
     P.coo_len = coo;
     // one packet of padding: the kernel prefetches a slice's first packet with
     // every lane before it knows how many lanes the packet really has
     P.vals.assign((size_t)off + 256, V(0));
-    P.slots.assign((size_t)off + 256, 0);
+    P.slots.assign((size_t)soff + 256, 0);
     P.cvals.assign((size_t)coo + 256, V(0));
     P.crows.assign((size_t)coo + 256, 0);
     P.ccols.assign((size_t)coo + 256, 0);
   }
+  pt.lap("core: vrows + sizes");
   bool dup_error = false;
 #pragma omp parallel
   {
@@ -510,7 +580,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
       };
       build_vrows(t, vr);
       V *tv = P.vals.data() + t.nnz_off;
-      uint16_t *ts = P.slots.data() + t.nnz_off;
+      uint16_t *ts = P.slots.data() + t.sl_off;
       std::vector<std::vector<int32_t>> low(kLanes);
       for (int s = 0; s < t.nslices; s++) {
         int p0 = s * kLanes, m = std::min(kLanes, (int)t.nvrows - p0);
@@ -527,17 +597,23 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
               if (colind[j] == i) d = values[j]; // last duplicate wins, like :1292
           P.diag[t.vrow_off + p0 + l] = d;
         }
-        int64_t o = P.slice_meta[t.slice_base + s].off;
+        const SliceMeta &sm = P.slice_meta[t.slice_base + s];
+        int64_t o = sm.voff, os = sm.soff_cnt0 & 0x1ffffff;
         for (int g = 0; g < amax; g++) {
           int cnt = 0;
           while (cnt < m && vr[p0 + cnt].a > g) cnt++;
-          for (int l = 0; l < cnt; l++)
+          int lead = -1; // index of lane l's leader among the leaders of this packet
+          for (int l = 0; l < cnt; l++) {
+            const bool is_leader = (sm.leaders >> l) & 1;
+            if (is_leader) lead++;
             for (int j = 0; j < kPacket; j++) {
               int q = low[l][(vr[p0 + l].k0 + g) * kPacket + j];
               tv[o + packet_val_pos<V>(l, j, cnt)] = values[q];
-              ts[o + packet_slot_pos(l, j)] = slot_of(colind[q]);
+              if (is_leader) ts[os + packet_slot_pos(lead, j)] = slot_of(colind[q]);
             }
+          }
           o += 4 * (int64_t)cnt;
+          os += 4 * (int64_t)(lead + 1);
         }
       }
       // COO leftovers: the last len%4 lower entries of every row, natural row
@@ -569,6 +645,10 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     return false;
   }
 
+  pt.lap("core: fill streams");
+  if (getenv("CFS_PLAN_VERBOSE"))
+    fprintf(stderr, "[cfs_plan] slot stream %lld entries for %lld value entries\n",
+            (long long)P.slot_len, (long long)P.stream_len);
   // ---- halo fold index: strips -> destination rows, fixed order --------------
   {
     const int64_t H = P.nhalo;
@@ -611,6 +691,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     }
   }
 
+  pt.lap("core: fold index");
   // ---- LDS window: the largest tile decides --------------------------------
   {
     int lds_slots = 64;
@@ -752,8 +833,10 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   if (ngroups > by_rows) ngroups = by_rows;
   if (ngroups < 8) ngroups = 8;
 
+  PhaseTimer pt;
   std::vector<int32_t> perm, chunk;
   cluster_rows<V>(n, rowptr, colind, rb, re, ngroups, opt.group_share, perm, chunk);
+  pt.lap("cluster_rows");
   std::vector<int32_t> inv(rows);
   for (int p = 0; p < rows; p++) inv[perm[p] - rb] = rb + p;
   // the lower triangle + diagonal in schedule space, from the ORIGINAL lower
@@ -807,6 +890,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
       }
     }
   }
+  pt.lap("schedule-space matrix");
   if (!build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in,
                           opt, &chunk, &perm, P))
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
@@ -872,7 +956,7 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
   const int rb = P.row_begin;
   for (const Tile &t : P.tiles) {
     const V *tv = P.vals.data() + t.nnz_off;
-    const uint16_t *ts = P.slots.data() + t.nnz_off;
+    const uint16_t *ts = P.slots.data() + t.sl_off;
     auto slot_col = [&](int s) {
       return s < t.nown ? t.row0 + s : P.halo_col[t.halo_off + (s - t.nown)];
     };
@@ -887,16 +971,21 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
         r[l] = info & 0xffff;
         a[l] = info >> 16;
       }
-      int64_t o = P.slice_meta[t.slice_base + s].off;
+      const SliceMeta &sm = P.slice_meta[t.slice_base + s];
+      int64_t o = sm.voff, os = sm.soff_cnt0 & 0x1ffffff;
       int amax = a[0];
       for (int g = 0; g < amax; g++) {
         int cnt = 0;
         while (cnt < kLanes && a[cnt] > g) cnt++;
-        for (int l = 0; l < cnt; l++)
+        int lead = -1;
+        for (int l = 0; l < cnt; l++) {
+          if ((sm.leaders >> l) & 1) lead++;
           for (int j = 0; j < kPacket; j++)
-            rows_out[r[l]].push_back({slot_col(ts[o + packet_slot_pos(l, j)]),
+            rows_out[r[l]].push_back({slot_col(ts[os + packet_slot_pos(lead, j)]),
                                       tv[o + packet_val_pos<V>(l, j, cnt)]});
+        }
         o += 4 * (int64_t)cnt;
+        os += 4 * (int64_t)(lead + 1);
       }
     }
     const V *cv = P.cvals.data() + t.coo_off;

@@ -35,6 +35,12 @@ for cfg in cfgs:
     print("  wave spread at last tile end (max-min per WG)", q(w.max(1) - w.min(1)))
     print("  first wave done", q(w.min(1)), "| last wave done", q(w.max(1)))
     end = us[:, 3]; dur = us[:, 3] - us[:, 1]
+    shift = int(os.environ.get("CFS_XCD_SHIFT", "0"))
+    nper = ng.value // 8
+    grp = ((np.arange(ng.value) + shift) % 8) * nper + np.arange(ng.value) // 8
+    for k in range(8):
+        sel = grp // nper == k
+        print("   row-range  %d: end mean %.1f std %.1f" % (k, end[sel].mean(), end[sel].std()))
     for k in range(8):
         sel = np.arange(ng.value) % 8 == k
         print("   xcd-label %d: end mean %.1f std %.1f | stream-phase mean %.1f std %.1f" % (k, end[sel].mean(), end[sel].std(), dur[sel].mean(), dur[sel].std()))
