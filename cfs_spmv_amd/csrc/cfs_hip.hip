@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(BLOCK)
                         const uint16_t *__restrict__ a_slots, const V *__restrict__ a_cvals,
                         const uint16_t *__restrict__ a_crows,
                         const uint16_t *__restrict__ a_ccols, V *__restrict__ a_strip,
-                        const int a_row_begin, const int a_lds_slots, const int xcd_shift,
+                        const int a_row_begin, const int a_lds_slots,
                         const V *__restrict__ x, V *__restrict__ y,
                         unsigned long long *__restrict__ dbg) {
   // every array is a separate __restrict__ argument: read-only metadata at
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(BLOCK)
   // contiguous run of groups so neighbouring tiles share halo lines in one L2.
   // Placement only affects speed, never correctness.
   const int nper = gridDim.x >> 3;
-  const int g = (((int)blockIdx.x + xcd_shift) & 7) * nper + (blockIdx.x >> 3);
+  const int g = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
   const int t0 = d.group_ptr[g], t1 = d.group_ptr[g + 1];
   // developer timeline (cfs_hip_sym_debug_timeline): 100 MHz wall clock stamps of
   // this workgroup's phases; dbg is NULL in every product launch
@@ -399,18 +399,41 @@ __global__ void __launch_bounds__(BLOCK)
   if (dbg && tid == 0) dbg[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
-// halo fold: y[dst] += sum of the strip entries aimed at dst, in fixed order
+// halo fold: y[dst] += sum of the strip entries aimed at dst, in a fixed order:
+// a lane sums the first 8 entries of its destination's list itself; what is
+// left of a long list (a hub row collects contributions from many tiles) is
+// summed by the whole wave, strided, with a fixed shuffle tree -- one slow lane
+// would otherwise decide the duration of the launch.
 template <typename V>
 __global__ void __launch_bounds__(256)
     cfs_fold_kernel(V *__restrict__ y, const V *__restrict__ src,
                     const int32_t *__restrict__ frow, const int32_t *__restrict__ fptr,
                     const int32_t *__restrict__ fidx, int m) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= m) return;
-  const int r = frow[i];
-  V s = y[r];
-  for (int q = fptr[i]; q < fptr[i + 1]; ++q) s += src[fidx[q]];
-  y[r] = s;
+  const int lane = threadIdx.x & 63;
+  int r = 0, b = 0, e = 0;
+  V s = V(0);
+  if (i < m) {
+    r = frow[i];
+    b = fptr[i];
+    e = fptr[i + 1];
+    s = y[r];
+  }
+  const int own_end = min(e, b + 8);
+  for (int q = b; q < own_end; ++q) s += src[fidx[q]];
+  unsigned long long need = __ballot(e > own_end);
+  while (need) {
+    const int L = __ffsll((long long)need) - 1;
+    need &= need - 1;
+    const int lb = __shfl(own_end, L), le = __shfl(e, L);
+    V p = V(0);
+    for (int q = lb + lane; q < le; q += 64) p += src[fidx[q]];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) p += __shfl_down(p, o);
+    const V tot = __shfl(p, 0);
+    if (lane == L) s += tot;
+  }
+  if (i < m) y[r] = s;
 }
 
 // pack contributions for rows owned by lower ranks: one value per remote row
@@ -540,7 +563,6 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int nfold = 0, nsend = 0, nrfold = 0;
   int ablate_mode = 0; // cfs_hip_options.flags & 7 (timing-only ablations)
   unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
-  int xcd_shift = getenv("CFS_XCD_SHIFT") ? atoi(getenv("CFS_XCD_SHIFT")) : 0; // experiment knob
   size_t lds_bytes = 0;
   int64_t halo_slots = 0, stream_len = 0, slot_len = 0, nslices = 0, coo_len = 0;
 
@@ -628,27 +650,27 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 1>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else if (mode == 2)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 2>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else if (mode == 3)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 3>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else if (mode == 4)
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 4>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
     else
       hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 0>), dim3(P.ngroups), dim3(BLOCK),
                          lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                          dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, xcd_shift, x, y, dbg_buf);
+                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
   }
 
   int spmv_local(void *yv, const void *xv, void *sendv, hipStream_t st, int phases) override {
@@ -847,6 +869,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     r.block_threads = o->block_threads;
     r.flags = o->flags;
     r.reorder = !(o->flags & CFS_HIP_FLAG_NO_REORDER);
+    if (o->flags & CFS_HIP_FLAG_FORCE_CLUSTER) r.force_order = 2;
   }
   return r;
 }

@@ -82,6 +82,8 @@ typedef struct {
 /* keep rows in their given order (tiles = runs of consecutive rows) instead of
  * clustering the matrix graph first (the default, fewer halo columns)        */
 #define CFS_HIP_FLAG_NO_REORDER 8
+/* always keep the clustered order (skip the halo-count comparison)            */
+#define CFS_HIP_FLAG_FORCE_CLUSTER 16
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->

@@ -35,7 +35,7 @@ for cfg in cfgs:
     print("  wave spread at last tile end (max-min per WG)", q(w.max(1) - w.min(1)))
     print("  first wave done", q(w.min(1)), "| last wave done", q(w.max(1)))
     end = us[:, 3]; dur = us[:, 3] - us[:, 1]
-    shift = int(os.environ.get("CFS_XCD_SHIFT", "0"))
+    shift = 0
     nper = ng.value // 8
     grp = ((np.arange(ng.value) + shift) % 8) * nper + np.arange(ng.value) // 8
     for k in range(8):
