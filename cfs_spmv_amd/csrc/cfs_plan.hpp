@@ -189,7 +189,7 @@ template <typename V>
 bool build_plan_core(int n, const int *rowptr, const int *colind, const V *values,
                      int nranks, int rank, const int *row_splits_in,
                      const Options &opt, const std::vector<int32_t> *chunks_in,
-                     const std::vector<int32_t> *perm_in, SymPlan<V> &P) {
+                     const std::vector<int32_t> *perm_in, SymPlan<V> &P, bool cut_only = false) {
   P = SymPlan<V>();
   P.n = n;
   P.nranks = nranks;
@@ -286,76 +286,98 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     }
     chunk[ngroups] = re;
 
-    std::vector<int32_t> stamp(n > 0 ? n : 1, -1);
-    int tid = 0;
     // greedy cut of rows [r0, r1) under the slot budget and a cost cap; returns
-    // false on an unschedulable row
-    auto cut = [&](int r0, int r1, int64_t cap, std::vector<Tile> &out) -> bool {
-      int row = r0;
-      while (row < r1) {
-        Tile t{};
-        t.row0 = row;
-        int nown = 0, nhalo = 0;
-        int64_t nnz = 0, c0 = cost[row - rb];
+    // false on an unschedulable row.  Chunks are independent: one thread each,
+    // with its own "column already counted for tile id" stamps.
+    std::vector<std::vector<Tile>> per_group(ngroups);
+    std::string cut_error;
+#pragma omp parallel
+    {
+      std::vector<int32_t> stamp(n > 0 ? n : 1, -1);
+      int tid = 0;
+      std::string err;
+      auto cut = [&](int r0, int r1, int64_t cap, std::vector<Tile> &out) -> bool {
+        int row = r0;
         while (row < r1) {
-          int newh = 0, len = 0;
-          for (int j = rowptr[row]; j < rowptr[row + 1]; j++) {
-            int c = colind[j];
-            if (c >= row) continue;
-            len++;
-            if (c < t.row0 && stamp[c] != tid) {
-              stamp[c] = tid;
-              newh++;
+          Tile t{};
+          t.row0 = row;
+          int nown = 0, nhalo = 0;
+          int64_t nnz = 0, c0 = cost[row - rb];
+          while (row < r1) {
+            int newh = 0, len = 0;
+            for (int j = rowptr[row]; j < rowptr[row + 1]; j++) {
+              int c = colind[j];
+              if (c >= row) continue;
+              len++;
+              if (c < t.row0 && stamp[c] != tid) {
+                stamp[c] = tid;
+                newh++;
+              }
             }
-          }
-          if (len > 65535) {
-            P.error = "row with more than 65535 lower entries";
-            return false;
-          }
-          bool fits = (nown + 1 + nhalo + newh <= max_slots) &&
-                      (nnz + len <= max_tile_nnz || nown == 0) && nown < 65535 &&
-                      (cost[row + 1 - rb] - c0 <= cap || nown == 0);
-          if (!fits) {
-            if (nown == 0) {
-              P.error = "a single row needs more LDS slots than max_slots "
-                        "(dense row): unsupported by the tile schedule";
+            if (len > 65535) {
+              err = "row with more than 65535 lower entries";
               return false;
             }
-            break; // stale stamps are harmless: the next tile uses tid + 1
+            bool fits = (nown + 1 + nhalo + newh <= max_slots) &&
+                        (nnz + len <= max_tile_nnz || nown == 0) && nown < 65535 &&
+                        (cost[row + 1 - rb] - c0 <= cap || nown == 0);
+            if (!fits) {
+              if (nown == 0) {
+                err = "a single row needs more LDS slots than max_slots "
+                      "(dense row): unsupported by the tile schedule";
+                return false;
+              }
+              break; // stale stamps are harmless: the next tile uses tid + 1
+            }
+            nown++;
+            nhalo += newh;
+            nnz += len;
+            row++;
           }
-          nown++;
-          nhalo += newh;
-          nnz += len;
-          row++;
+          t.nown = nown;
+          t.nslots = nown + nhalo;
+          t.nslices = (nown + kLanes - 1) / kLanes;
+          out.push_back(t);
+          tid++;
         }
-        t.nown = nown;
-        t.nslots = nown + nhalo;
-        t.nslices = (nown + kLanes - 1) / kLanes;
-        out.push_back(t);
-        tid++;
+        return true;
+      };
+#pragma omp for schedule(dynamic, 1)
+      for (int g = 0; g < ngroups; g++) {
+        const int r0 = chunk[g], r1 = chunk[g + 1];
+        if (r0 >= r1 || !err.empty()) continue;
+        std::vector<Tile> &tmp = per_group[g];
+        if (!cut(r0, r1, (int64_t)1 << 60, tmp)) continue;
+        if (tmp.size() > 1) { // even the tiles of a chunk out (less halo, same count)
+          const int64_t cc = cost[r1 - rb] - cost[r0 - rb];
+          std::vector<Tile> even;
+          if (!cut(r0, r1, cc / (int64_t)tmp.size() + cc / 64 + 1, even)) continue;
+          if (even.size() <= tmp.size()) tmp.swap(even);
+        }
       }
-      return true;
-    };
+      if (!err.empty()) {
+#pragma omp critical
+        cut_error = err;
+      }
+    }
+    if (!cut_error.empty()) {
+      P.error = cut_error;
+      return false;
+    }
     P.group_ptr.assign(ngroups + 1, 0);
-    std::vector<Tile> tmp;
     for (int g = 0; g < ngroups; g++) {
-      const int r0 = chunk[g], r1 = chunk[g + 1];
       P.group_ptr[g] = (int32_t)P.tiles.size();
-      if (r0 >= r1) continue;
-      tmp.clear();
-      if (!cut(r0, r1, (int64_t)1 << 60, tmp)) return false;
-      if (tmp.size() > 1) { // even the tiles of a chunk out (less halo, same count)
-        const int64_t cc = cost[r1 - rb] - cost[r0 - rb];
-        std::vector<Tile> even;
-        if (!cut(r0, r1, cc / (int64_t)tmp.size() + cc / 64 + 1, even)) return false;
-        if (even.size() <= tmp.size()) tmp.swap(even);
-      }
-      P.tiles.insert(P.tiles.end(), tmp.begin(), tmp.end());
+      P.tiles.insert(P.tiles.end(), per_group[g].begin(), per_group[g].end());
     }
     P.group_ptr[ngroups] = (int32_t)P.tiles.size();
   }
   const int T = (int)P.tiles.size();
   pt.lap("core: cut tiles");
+  if (cut_only) { // the caller only wants to compare halo sizes of two row orders
+    P.nhalo = 0;
+    for (const Tile &t : P.tiles) P.nhalo += t.nslots - t.nown;
+    return true;
+  }
 
   // ---- virtual rows: one lane each ----------------------------------------------
   // A lane normally owns a whole row.  A row much longer than its neighbours
@@ -403,7 +425,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 #pragma omp parallel
     {
       std::vector<VRow> vr;
-#pragma omp for schedule(dynamic, 8)
+#pragma omp for schedule(dynamic, 1)
       for (int ti = 0; ti < T; ti++) {
         Tile &t = P.tiles[ti];
         build_vrows(t, vr);
@@ -462,7 +484,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   {
     std::vector<VRow> vr;
     std::vector<int32_t> prev, cur;
-#pragma omp for schedule(dynamic, 8)
+#pragma omp for schedule(dynamic, 1)
     for (int ti = 0; ti < T; ti++) {
       Tile &t = P.tiles[ti];
       build_vrows(t, vr);
@@ -540,7 +562,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
     std::vector<int32_t> hcols, lowj;
     std::vector<VRow> vr;
-#pragma omp for schedule(dynamic, 8)
+#pragma omp for schedule(dynamic, 1)
     for (int ti = 0; ti < T; ti++) {
       const Tile &t = P.tiles[ti];
       // halo: unique columns < row0, ascending
@@ -833,78 +855,113 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   pt.lap("cluster_rows");
   std::vector<int32_t> inv(rows);
   for (int p = 0; p < rows; p++) inv[perm[p] - rb] = rb + p;
-  // the lower triangle + diagonal in schedule space, from the ORIGINAL lower
-  // entries only (col <= row), each placed at (later, earlier) of its two ends
+  // the lower triangle + diagonal in schedule space.  Row p of it holds the
+  // neighbours of its original row that are numbered before p (or lie left of
+  // the block); every VALUE is taken from the original LOWER triangle (the
+  // entry (max(i,c), min(i,c))), which is all the reference's SSS path reads.
+  // Rows are independent: counted, filled and sorted in parallel.
+  auto lower_value_pos = [&](int hi, int lo) -> int { // position of (hi, lo), hi > lo
+    int b = rowptr[hi], e = rowptr[hi + 1];
+    int l = b, r = e;
+    while (l < r) { // columns usually ascend: binary search first
+      int m = (l + r) >> 1;
+      if (colind[m] < lo) l = m + 1;
+      else r = m;
+    }
+    if (l < e && colind[l] == lo) return l;
+    for (int j = b; j < e; j++)
+      if (colind[j] == lo) return j; // unsorted row
+    return -1;
+  };
   std::vector<int32_t> brp((size_t)n + 2, 0);
-  for (int i = rb; i < re; i++) {
-    const int pi = inv[i - rb];
+#pragma omp parallel for schedule(static)
+  for (int p = rb; p < re; p++) {
+    const int i = perm[p - rb];
+    int cnt = 0;
     for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
       const int c = colind[j];
-      if (c > i) continue;
-      const int pc = c >= rb ? inv[c - rb] : c;
-      brp[std::max(pi, pc) + 1]++;
+      if (c == i || c < rb) cnt++;
+      else if (c < re && inv[c - rb] < p) cnt++;
     }
+    brp[p + 1] = cnt;
   }
-  for (int i = rb; i <= re; i++) brp[i + 1] += brp[i]; // rows < rb are empty
+  for (int p = rb; p < re; p++) brp[p + 1] += brp[p]; // rows < rb are empty
   const int64_t bnnz = brp[re];
   std::vector<int32_t> bci((size_t)bnnz + 1);
   std::vector<V> bva((size_t)bnnz + 1);
-  {
-    std::vector<int32_t> fill(brp.begin(), brp.end());
-    for (int i = rb; i < re; i++) {
-      const int pi = inv[i - rb];
-      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-        const int c = colind[j];
-        if (c > i) continue;
-        const int pc = c >= rb ? inv[c - rb] : c;
-        const int q = fill[std::max(pi, pc)]++;
-        bci[q] = std::min(pi, pc);
-        bva[q] = values[j];
-      }
-    }
-  }
+  bool asym = false;
 #pragma omp parallel
   {
     std::vector<std::pair<int32_t, V>> tmp;
-#pragma omp for schedule(dynamic, 512)
-    for (int p = rb; p < re; p++) { // columns ascending; duplicates keep their order
-      const int b = brp[p], e = brp[p + 1];
-      bool sorted = true;
-      for (int q = b + 1; q < e && sorted; q++) sorted = bci[q - 1] <= bci[q];
-      if (sorted) continue;
-      tmp.resize(e - b);
-      for (int q = b; q < e; q++) tmp[q - b] = {bci[q], bva[q]};
+#pragma omp for schedule(dynamic, 256)
+    for (int p = rb; p < re; p++) {
+      const int i = perm[p - rb];
+      tmp.clear();
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        const int c = colind[j];
+        int col;
+        if (c == i) col = p;
+        else if (c < rb) col = c;
+        else if (c < re && inv[c - rb] < p) col = inv[c - rb];
+        else continue;
+        int src = j; // (i, c) with c <= i is a lower entry itself
+        if (c > i) {
+          src = lower_value_pos(c, i);
+          if (src < 0) {
+            asym = true; // structurally unsymmetric input: keep the natural order
+            src = j;
+          }
+        }
+        tmp.push_back({col, values[src]});
+      }
       std::stable_sort(tmp.begin(), tmp.end(),
                        [](const std::pair<int32_t, V> &x, const std::pair<int32_t, V> &y) {
                          return x.first < y.first;
                        });
-      for (int q = b; q < e; q++) {
-        bci[q] = tmp[q - b].first;
-        bva[q] = tmp[q - b].second;
+      int q = brp[p];
+      for (size_t k = 0; k < tmp.size(); k++) {
+        // duplicate entries (the reader keeps them) cannot be paired with their
+        // mirror images one to one: such matrices keep their natural order
+        if (k > 0 && tmp[k].first == tmp[k - 1].first) asym = true;
+        bci[q] = tmp[k].first;
+        bva[q] = tmp[k].second;
+        q++;
       }
     }
   }
-  pt.lap("schedule-space matrix");
-  if (!build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in,
-                          opt, &chunk, &perm, P))
+  if (asym)
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
-                              nullptr, nullptr, P); // e.g. a cluster row too dense: natural order
+                              nullptr, nullptr, P);
+  pt.lap("schedule-space matrix");
   // keep the clustered schedule only if it has at least 2.5x fewer halo slots:
   // clustered tiles pay for their compactness with scattered x / y accesses
   // (measured on MI355X, fp64: Flan stand-in 3.5x fewer halo slots -> 8 % faster;
   // pwtk stand-in 2.1x fewer -> 11 % slower; random sparsity has no locality to
   // find).  In fp32 the scattered 4-byte accesses weigh twice as much against a
   // stream half as long: the same 3.5x is 7 % slower, so the bar is 6x there.
+  // Only the tile cut of both orders is needed to decide.
+  bool use_clustered = true;
   if (opt.force_order != 2) {
-    std::vector<int32_t>().swap(bci);
-    std::vector<V>().swap(bva);
-    SymPlan<V> N;
-    if (build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
-                           nullptr, N) &&
-        (sizeof(V) == 8 ? 2 * N.nhalo <= 5 * P.nhalo : N.nhalo <= 6 * P.nhalo))
-      P = std::move(N);
+    SymPlan<V> C, N;
+    const bool c_ok = build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank,
+                                         row_splits_in, opt, &chunk, &perm, C, true);
+    const bool n_ok = build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in,
+                                         opt, nullptr, nullptr, N, true);
+    if (getenv("CFS_PLAN_VERBOSE"))
+      fprintf(stderr, "[cfs_plan] halo slots: clustered %lld, natural %lld\n",
+              c_ok ? (long long)C.nhalo : -1LL, n_ok ? (long long)N.nhalo : -1LL);
+    if (!c_ok) use_clustered = false;
+    else if (n_ok && (sizeof(V) == 8 ? 2 * N.nhalo <= 5 * C.nhalo : N.nhalo <= 6 * C.nhalo))
+      use_clustered = false;
   }
-  return true;
+  if (use_clustered &&
+      build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in, opt,
+                         &chunk, &perm, P))
+    return true;
+  std::vector<int32_t>().swap(bci);
+  std::vector<V>().swap(bva);
+  return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
+                            nullptr, P);
 }
 
 // Receive side of a shard: recv_rows[k] is the global row of the k-th value of

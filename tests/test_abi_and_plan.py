@@ -138,3 +138,37 @@ def test_shard_schedules(nranks):
     # nnz balance within 10 %
     per = [cfs.plan_check(n, rp, ci, va, nranks, r, rs)["nnz_low"] for r in range(nranks)]
     assert max(per) <= 1.1 * (low / nranks) + 1000
+
+
+def test_duplicates_and_unsymmetric_structure_keep_natural_order():
+    """the clustered order pairs every entry with its mirror image; input with
+    duplicate entries or a missing mirror entry must not be mangled by it"""
+    import scipy.sparse as sp
+    n = 600
+    rng = np.random.default_rng(5)
+    L = sp.random(n, n, density=0.02, random_state=2, format="coo")
+    L = sp.tril(L, k=-1).tocoo()
+    rows = np.concatenate([L.row, L.col, np.arange(n)])
+    cols = np.concatenate([L.col, L.row, np.arange(n)])
+    vals = np.concatenate([L.data, L.data, np.full(n, 3.0)])
+    # duplicate one lower entry (and its mirror) with a different value, like the
+    # Matrix-Market reader does for repeated lines
+    r0, c0 = int(L.row[0]), int(L.col[0])
+    rows = np.concatenate([rows, [r0, c0]])
+    cols = np.concatenate([cols, [c0, r0]])
+    vals = np.concatenate([vals, [0.123, 0.123]])
+    order = np.lexsort((np.arange(rows.size), cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    rp = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rp, rows + 1, 1)
+    rp = np.cumsum(rp).astype(np.int32)
+    rep = cfs.plan_check(n, rp, cols.astype(np.int32), vals, options=cfs.make_options(flags=16))
+    assert rep["mismatches"] == 0 and rep["decoded"] == L.nnz + 1
+    # structurally unsymmetric: drop one upper entry
+    keep = ~((rows == c0) & (cols == r0))
+    rp2 = np.zeros(n + 1, dtype=np.int32)
+    np.add.at(rp2, rows[keep] + 1, 1)
+    rp2 = np.cumsum(rp2).astype(np.int32)
+    rep = cfs.plan_check(n, rp2, cols[keep].astype(np.int32), vals[keep],
+                         options=cfs.make_options(flags=16))
+    assert rep["mismatches"] == 0
