@@ -82,11 +82,13 @@ int main(int argc, char **argv) {
   cout << "[INFO]: warming up caches..." << endl;
 #endif
   for (size_t i = 0; i < loops / 2; i++) spdmv(y, M, x, N);
+  synchronize();
 #ifdef _LOG_INFO
   cout << "[INFO]: benchmarking SpDMV using " << names[fmt] << "..." << endl;
 #endif
   tstart = omp_get_wtime();
-  for (size_t i = 0; i < loops; i++) spdmv(y, M, x, N); // each call returns synchronised
+  for (size_t i = 0; i < loops; i++) spdmv(y, M, x, N); // enqueued: x, y are device-resident
+  synchronize();                                        // ... so wait before stopping the clock
   const double compute_time = omp_get_wtime() - tstart;
   internal_copy(y_host, Platform::cpu, y, Platform::gpu, (size_t)M * sizeof(VALUE));
 

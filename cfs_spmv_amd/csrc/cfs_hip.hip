@@ -823,7 +823,8 @@ int cfs_hip_default_stream(void **stream) {
 int cfs_hip_synchronize(void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  // NULL: the library stream of the synchronous entry points
+  HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : g_stream));
   return 0;
 }
 
@@ -852,6 +853,7 @@ int cfs_hip_memcpy(void *dst, const void *src, size_t bytes, int dir) {
   hipMemcpyKind k = dir == CFS_HIP_H2D   ? hipMemcpyHostToDevice
                     : dir == CFS_HIP_D2H ? hipMemcpyDeviceToHost
                                          : hipMemcpyDeviceToDevice;
+  if (g_stream) HIPCHK(hipStreamSynchronize(g_stream)); // pending SpMVs on resident vectors
   HIPCHK(hipMemcpy(dst, src, bytes, k));
   return 0;
 }
@@ -1013,7 +1015,10 @@ int cfs_hip_sym_spmv(cfs_hip_sym_t h, void *y, const void *x) {
   if ((rc = cfs_hip_sym_spmv_async(h, ydev, xdev, g_stream))) return rc;
   if (!yd)
     HIPCHK(hipMemcpyAsync(y, ydev, (size_t)h->rows() * vb, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  // host memory involved: the result must be usable on return.  Device-resident
+  // x and y: the work is ordered on the library stream and the caller observes
+  // it through cfs_hip_memcpy / cfs_hip_synchronize (both wait for this stream).
+  if (!xd || !yd) HIPCHK(hipStreamSynchronize(g_stream));
   return 0;
 }
 
@@ -1280,7 +1285,7 @@ int cfs_hip_csr_spmv(cfs_hip_csr_t h, void *y, const void *x) {
   if ((rc = cfs_hip_csr_spmv_async(h, ydev, xdev, g_stream))) return rc;
   if (!yd)
     HIPCHK(hipMemcpyAsync(y, ydev, (size_t)h->nrows * vb, hipMemcpyDeviceToHost, g_stream));
-  HIPCHK(hipStreamSynchronize(g_stream));
+  if (!xd || !yd) HIPCHK(hipStreamSynchronize(g_stream));
   return 0;
 }
 

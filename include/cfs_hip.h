@@ -52,7 +52,7 @@ int cfs_hip_init(int device);
  * hipStream_t verbatim: NULL there means HIP's null stream (which is what
  * torch.cuda.current_stream() is by default), never this one.               */
 int cfs_hip_default_stream(void **stream);
-int cfs_hip_synchronize(void *stream);
+int cfs_hip_synchronize(void *stream); /* NULL = the library stream */
 
 /* ---- allocator (replaces internal_alloc / internal_free,
  *      src/allocator.cpp:8-43; Platform::gpu memory)                      ---- */
@@ -121,9 +121,13 @@ int cfs_hip_sym_destroy(cfs_hip_sym_t h);
  *      never zeroes it: test/test_spmv_mmf.cpp:71,82-83); x and y must not
  *      alias.  x has n entries, y has n entries (block rows for a shard).
  *
- * cfs_hip_sym_spmv      : x / y may be host or device pointers (detected);
- *                         host pointers take the slow staged path; the call
- *                         returns after the result is complete.
+ * cfs_hip_sym_spmv      : x / y may be host or device pointers (detected).
+ *                         With a host pointer the call stages through PCIe and
+ *                         returns after the result is complete.  With both
+ *                         vectors device-resident it is enqueued on the
+ *                         library stream and returns at once; cfs_hip_memcpy
+ *                         and cfs_hip_synchronize(NULL) wait for that stream,
+ *                         so a caller that reads y back always sees it done.
  * cfs_hip_sym_spmv_async: device pointers only, enqueued on `stream`
  *                         (a hipStream_t; NULL = HIP's null stream), returns
  *                         immediately.                                       */

@@ -21,6 +21,9 @@ size_t get_num_threads();
 int get_device();
 // number of HIP devices visible; 0 means the GPU path cannot run
 int get_num_devices();
+// wait for every SpMV enqueued on Platform::gpu vectors (a benchmark loop calls
+// this once before it stops its clock)
+void synchronize();
 // kept for API compatibility (the reference never calls it either)
 void setaffinity_oncpu(unsigned int cpu);
 

@@ -9,6 +9,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -60,9 +62,96 @@ struct Elem {
 
 } // namespace
 
+// ---- optional binary cache ------------------------------------------------------
+// Parsing Queen_4147 (~5 GB of text) dominates every run of the driver, so the
+// CSR can be kept as a side file: set CFS_MTX_CACHE_DIR to a writable directory
+// and <dir>/<basename>.<f32|f64>.csrbin is written after the first parse and
+// mapped on later runs.  The cache is keyed by the source file's size and
+// modification time; anything that does not match is ignored and rewritten.
+struct CacheHeader {
+  char magic[8]; // "CFSCSR1\0"
+  int64_t src_size, src_mtime_ns, nrows, ncols, nnz;
+  int32_t symmetric, value_bytes;
+};
+
+static std::string cache_path(const std::string &filename, size_t value_bytes) {
+  const char *dir = getenv("CFS_MTX_CACHE_DIR");
+  if (!dir || !*dir) return std::string();
+  size_t slash = filename.find_last_of('/');
+  std::string base = slash == std::string::npos ? filename : filename.substr(slash + 1);
+  return std::string(dir) + "/" + base + (value_bytes == 8 ? ".f64" : ".f32") + ".csrbin";
+}
+
+template <typename IndexType, typename ValueType>
+static bool cache_load(const std::string &path, const struct stat &src,
+                       CsrArrays<IndexType, ValueType> &out) {
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  CacheHeader h;
+  bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "CFSCSR1", 8) == 0 &&
+            h.src_size == (int64_t)src.st_size &&
+            h.src_mtime_ns == (int64_t)src.st_mtim.tv_sec * 1000000000LL + src.st_mtim.tv_nsec &&
+            h.value_bytes == (int32_t)sizeof(ValueType) && h.nrows >= 0 && h.nnz >= 0;
+  if (ok) {
+    out.nrows = (IndexType)h.nrows;
+    out.ncols = (IndexType)h.ncols;
+    out.nnz = h.nnz;
+    out.symmetric = h.symmetric != 0;
+    out.rowptr.resize((size_t)h.nrows + 1);
+    out.colind.resize((size_t)h.nnz);
+    out.values.resize((size_t)h.nnz);
+    ok = fread(out.rowptr.data(), sizeof(IndexType), out.rowptr.size(), f) == out.rowptr.size() &&
+         fread(out.colind.data(), sizeof(IndexType), out.colind.size(), f) == out.colind.size() &&
+         fread(out.values.data(), sizeof(ValueType), out.values.size(), f) == out.values.size();
+  }
+  fclose(f);
+  return ok;
+}
+
+template <typename IndexType, typename ValueType>
+static void cache_store(const std::string &path, const struct stat &src,
+                        const CsrArrays<IndexType, ValueType> &a) {
+  const std::string tmp = path + ".tmp";
+  FILE *f = fopen(tmp.c_str(), "wb");
+  if (!f) return; // the cache is best effort
+  CacheHeader h;
+  memset(&h, 0, sizeof h);
+  memcpy(h.magic, "CFSCSR1", 8);
+  h.src_size = (int64_t)src.st_size;
+  h.src_mtime_ns = (int64_t)src.st_mtim.tv_sec * 1000000000LL + src.st_mtim.tv_nsec;
+  h.nrows = a.nrows;
+  h.ncols = a.ncols;
+  h.nnz = a.nnz;
+  h.symmetric = a.symmetric ? 1 : 0;
+  h.value_bytes = (int32_t)sizeof(ValueType);
+  bool ok = fwrite(&h, sizeof h, 1, f) == 1 &&
+            fwrite(a.rowptr.data(), sizeof(IndexType), a.rowptr.size(), f) == a.rowptr.size() &&
+            fwrite(a.colind.data(), sizeof(IndexType), a.colind.size(), f) == a.colind.size() &&
+            fwrite(a.values.data(), sizeof(ValueType), a.values.size(), f) == a.values.size();
+  ok = fclose(f) == 0 && ok;
+  if (ok) ok = rename(tmp.c_str(), path.c_str()) == 0;
+  if (!ok) remove(tmp.c_str());
+}
+
+template <typename IndexType, typename ValueType>
+static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueType> &out,
+                        std::string &error);
+
 template <typename IndexType, typename ValueType>
 bool LoadMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueType> &out,
                 std::string &error) {
+  const std::string cpath = cache_path(filename, sizeof(ValueType));
+  struct stat st;
+  const bool have_stat = stat(filename.c_str(), &st) == 0;
+  if (!cpath.empty() && have_stat && cache_load<IndexType, ValueType>(cpath, st, out)) return true;
+  if (!ParseMmfCsr<IndexType, ValueType>(filename, out, error)) return false;
+  if (!cpath.empty() && have_stat) cache_store<IndexType, ValueType>(cpath, st, out);
+  return true;
+}
+
+template <typename IndexType, typename ValueType>
+static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueType> &out,
+                        std::string &error) {
   Mapped m;
   m.fd = open(filename.c_str(), O_RDONLY);
   if (m.fd < 0) {

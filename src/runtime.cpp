@@ -34,6 +34,13 @@ int get_num_devices() {
   return n;
 }
 
+void synchronize() {
+  if (cfs_hip_synchronize(nullptr) != 0) {
+    std::cout << "[ERROR]: " << cfs_hip_last_error() << std::endl;
+    exit(1);
+  }
+}
+
 void setaffinity_oncpu(unsigned int cpu) {
   cpu_set_t mask;
   CPU_ZERO(&mask);

@@ -113,3 +113,33 @@ def test_drivers_end_to_end(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "build", "test_spmv_mmf"), g, "1"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout + r.stderr
+
+
+def test_binary_cache_roundtrip(tmp_path, monkeypatch):
+    """CFS_MTX_CACHE_DIR: second load comes from <dir>/<file>.f64.csrbin, a touched
+    source file invalidates it"""
+    from cfs_spmv_amd import synth
+    n, rp, ci, va, _ = synth.generate("pwtk", 0.02)
+    p = str(tmp_path / "m.mtx")
+    synth.write_mtx(p, n, rp, ci, va)
+    cdir = tmp_path / "cache"
+    cdir.mkdir()
+    monkeypatch.setenv("CFS_MTX_CACHE_DIR", str(cdir))
+    a = cxx_load(p)
+    cache = cdir / "m.mtx.f64.csrbin"
+    assert cache.exists()
+    b = cxx_load(p)  # served by the cache
+    for k in ("rowptr", "colind", "values"):
+        assert np.array_equal(a[k], b[k])
+    assert a["nnz"] == b["nnz"] and a["symmetric"] == b["symmetric"]
+    # corrupt the cached values: proves the second path really reads the cache
+    raw = bytearray(cache.read_bytes())
+    raw[-8:] = np.float64(123.5).tobytes()
+    cache.write_bytes(bytes(raw))
+    c = cxx_load(p)
+    assert c["values"][-1] == 123.5
+    # a changed source file (size/mtime) invalidates the cache
+    with open(p, "a") as f:
+        f.write("% trailing comment\n")
+    d = cxx_load(p)
+    assert d["values"][-1] == a["values"][-1]
