@@ -1,0 +1,80 @@
+"""Parity at BASELINE.json's FULL sizes through size-independent properties
+(the CPU oracle would need minutes per case here):
+
+  * agreement with the general-CSR GPU kernel on the full (both-triangle) matrix
+    -- an independent code path (cfs_csr_stream_kernel) and an independent
+    storage of the same operator,
+  * symmetry of the operator:  <A x, z> == <x, A z>,
+  * linearity:  A (a x + b z) == a A x + b A z,
+  * a probe column: A e_j equals column j of the CSR arrays (exactly),
+  * y is fully overwritten (poisoned before every call).
+
+Tolerances are relative to max(|y|, sum_j |a_ij||x_j|) as in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+CASES = [("pdb1HYS", np.float64), ("pwtk", np.float64), ("ldoor", np.float64),
+         ("Flan_1565", np.float64), ("Queen_4147", np.float32)]
+
+
+@pytest.mark.parametrize("name,dtype", CASES, ids=[c[0] for c in CASES])
+def test_full_size_properties(name, dtype):
+    import torch
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    assert torch.cuda.is_available()
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    n, rp, ci, va, low = synth.generate(name, 1.0)
+    va = va.astype(dtype, copy=False)
+    A = cfs.SymMatrix(n, rp, ci, va)
+    st = A.stats()
+    assert st["nnz_low"] == low and st["nnz_full"] == rp[-1]
+    G = cfs.CsrMatrix(n, n, rp, ci, va)
+    # |A| |x| scale from the CSR kernel on absolute values
+    Gabs = cfs.CsrMatrix(n, n, rp, ci, np.abs(va))
+
+    def sym(xt):
+        y = torch.full((n,), float("nan"), dtype=tdt, device="cuda")
+        A.dense_vector_multiply(y, xt)
+        return y
+
+    def csr(M, xt):
+        y = torch.full((n,), float("nan"), dtype=tdt, device="cuda")
+        M.dense_vector_multiply(y, xt)
+        return y
+
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    x = (torch.rand(n, generator=gen, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+    z = (torch.rand(n, generator=gen, device="cuda", dtype=torch.float64) * 2 - 1).to(tdt)
+    y, yz = sym(x), sym(z)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y).all() and torch.isfinite(yz).all()
+    scale = torch.maximum(csr(Gabs, x.abs()), y.abs()).clamp_min(1e-300).double()
+    # (1) independent kernel + independent storage
+    y_csr = csr(G, x)
+    assert float(((y - y_csr).double().abs() / scale).max()) <= tol
+    # (2) symmetry of the operator (fp64 accumulation of the inner products)
+    lhs = torch.dot(y.double(), z.double())
+    rhs = torch.dot(x.double(), yz.double())
+    norm = torch.dot(csr(Gabs, x.abs()).double(), z.abs().double())
+    assert abs(float(lhs - rhs)) <= 50 * tol * float(norm)
+    # (3) linearity
+    a, b = 0.75, -1.5
+    comb = sym((a * x + b * z).to(tdt))
+    scale2 = (abs(a) * scale + abs(b) *
+              torch.maximum(csr(Gabs, z.abs()), yz.abs()).double()).clamp_min(1e-300)
+    assert float(((comb - (a * y + b * yz)).double().abs() / scale2).max()) <= 4 * tol
+    # (4) probe columns: A e_j is column j (= row j, symmetric) of the CSR, exactly
+    for j in (0, n // 3, n - 1):
+        e = torch.zeros(n, dtype=tdt, device="cuda")
+        e[j] = 1.0
+        col = sym(e).cpu().numpy()
+        ref = np.zeros(n, dtype=dtype)
+        ref[ci[rp[j]:rp[j + 1]]] = va[rp[j]:rp[j + 1]]
+        assert np.array_equal(col, ref)
+    A.close()
+    G.close()
+    Gabs.close()
