@@ -58,7 +58,8 @@ SYMBOLS = [
 
 
 def lib_path():
-    return os.path.join(HERE, "libcfs_hip.so")
+    # CFS_HIP_LIB: developer override to A/B an experimental build of the library
+    return os.environ.get("CFS_HIP_LIB") or os.path.join(HERE, "libcfs_hip.so")
 
 
 def load():

@@ -83,21 +83,41 @@ template <typename V> struct Pkt {
 __device__ __forceinline__ int leader_rank(unsigned long long leaders, int l) {
   return __popcll(leaders & (~0ull >> (63 - l))) - 1;
 }
+// The matrix stream is read exactly once per SpMV: the loads carry the
+// non-temporal hint so that they do not displace x, y, the slot tables and the
+// strips from L2 / Infinity Cache.
+typedef double cfs_d2 __attribute__((ext_vector_type(2)));
+typedef float cfs_f4 __attribute__((ext_vector_type(4)));
+typedef unsigned short cfs_us4 __attribute__((ext_vector_type(4)));
+#ifndef CFS_NT_STREAM
+#define CFS_NT_STREAM 1
+#endif
+template <typename T> __device__ __forceinline__ T stream_load(const T *p) {
+#if CFS_NT_STREAM
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
 __device__ __forceinline__ void fetch_packet(Pkt<double> &p, const double *tv,
                                              const uint16_t *ts, uint32_t off, uint32_t soff,
                                              int cnt, unsigned long long leaders, int lane) {
   const int ll = min(lane, max(cnt, 1) - 1);
-  const double2 lo = *reinterpret_cast<const double2 *>(tv + off + ll * 2);
-  const double2 hi = *reinterpret_cast<const double2 *>(tv + off + 2 * cnt + ll * 2);
-  p.c = *reinterpret_cast<const ushort4 *>(ts + soff + leader_rank(leaders, ll) * 4);
+  const cfs_d2 lo = stream_load(reinterpret_cast<const cfs_d2 *>(tv + off + ll * 2));
+  const cfs_d2 hi = stream_load(reinterpret_cast<const cfs_d2 *>(tv + off + 2 * cnt + ll * 2));
+  const cfs_us4 c =
+      stream_load(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
+  p.c = make_ushort4(c.x, c.y, c.z, c.w);
   p.v[0] = lo.x; p.v[1] = lo.y; p.v[2] = hi.x; p.v[3] = hi.y;
 }
 __device__ __forceinline__ void fetch_packet(Pkt<float> &p, const float *tv,
                                              const uint16_t *ts, uint32_t off, uint32_t soff,
                                              int cnt, unsigned long long leaders, int lane) {
   const int ll = min(lane, max(cnt, 1) - 1);
-  const float4 q = *reinterpret_cast<const float4 *>(tv + off + ll * 4);
-  p.c = *reinterpret_cast<const ushort4 *>(ts + soff + leader_rank(leaders, ll) * 4);
+  const cfs_f4 q = stream_load(reinterpret_cast<const cfs_f4 *>(tv + off + ll * 4));
+  const cfs_us4 c =
+      stream_load(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
+  p.c = make_ushort4(c.x, c.y, c.z, c.w);
   p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
 }
 // entries of the packet's slot block = 4 x (leaders among its cnt lanes)
@@ -263,8 +283,8 @@ __global__ void __launch_bounds__(BLOCK)
       meta_c = smeta[s];
       if (s_n < nsl) meta_n = smeta[s_n];
       const int p0 = s * 64 + lane, q0 = min(p0, nvr - 1);
-      const uint32_t i0 = d.rowinfo[vrow0 + q0]; // unconditional, clamped
-      const V d0 = d.diag[vrow0 + q0];
+      const uint32_t i0 = stream_load(d.rowinfo + vrow0 + q0); // unconditional, clamped
+      const V d0 = stream_load(d.diag + vrow0 + q0);
       info_c = p0 < nvr ? i0 : 0u;
       dg_c = p0 < nvr ? d0 : V(0);
       fetch_packet(N, tv, ts, meta_c.x, meta_c.y & 0x1ffffffu, (int)(meta_c.y >> 25),
@@ -278,7 +298,10 @@ __global__ void __launch_bounds__(BLOCK)
     if (wave < ncp) {
       fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)wave * 256u,
                    (uint32_t)wave * 256u, 64, ~0ull, lane);
-      Cr = *reinterpret_cast<const ushort4 *>(d.crows + t.coo_off + wave * 256 + lane * 4);
+      {
+        const cfs_us4 rr = stream_load(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + wave * 256 + lane * 4));
+        Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
+      }
     }
     // flush the previous tile's y window and refill both windows.  A thread
     // owns the same slot indices in both steps, so no barrier is needed between.
@@ -317,8 +340,8 @@ __global__ void __launch_bounds__(BLOCK)
       const bool have_next = s_n < nsl;
       if (have_next) { // next slice: header + head packet, a whole slice ahead
         const int pn = s_n * 64 + lane, qn = min(pn, nvr - 1);
-        const uint32_t in_ = d.rowinfo[vrow0 + qn]; // unconditional, clamped
-        const V dn = d.diag[vrow0 + qn];
+        const uint32_t in_ = stream_load(d.rowinfo + vrow0 + qn); // unconditional, clamped
+        const V dn = stream_load(d.diag + vrow0 + qn);
         info_c = pn < nvr ? in_ : 0u;
         dg_c = pn < nvr ? dn : V(0);
         fetch_packet(N, tv, ts, meta_n.x, meta_n.y & 0x1ffffffu, (int)(meta_n.y >> 25),
@@ -371,7 +394,8 @@ __global__ void __launch_bounds__(BLOCK)
       if (cp + NW < ncp) {
         fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)(cp + NW) * 256u,
                      (uint32_t)(cp + NW) * 256u, 64, ~0ull, lane);
-        Cr = *reinterpret_cast<const ushort4 *>(d.crows + t.coo_off + (cp + NW) * 256 + lane * 4);
+        const cfs_us4 rr = stream_load(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + (cp + NW) * 256 + lane * 4));
+        Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
       }
       const int e0 = cp * 256 + lane * 4;
       if (e0 + 0 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[0], Qr.x, Q.c.x);
