@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(BLOCK)
 }
 
 // halo fold: y[dst] += sum of the strip entries aimed at dst, in a fixed order:
-// a lane sums the first 8 entries of its destination's list itself; what is
+// a lane sums the first 16 entries of its destination's list itself; what is
 // left of a long list (a hub row collects contributions from many tiles) is
 // summed by the whole wave, strided, with a fixed shuffle tree -- one slow lane
 // would otherwise decide the duration of the launch.
@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(256)
     e = fptr[i + 1];
     s = y[r];
   }
-  const int own_end = min(e, b + 8);
+  const int own_end = min(e, b + 16);
   for (int q = b; q < own_end; ++q) s += src[fidx[q]];
   unsigned long long need = __ballot(e > own_end);
   while (need) {

@@ -708,6 +708,19 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   }
 
   pt.lap("core: fold index");
+  if (getenv("CFS_PLAN_VERBOSE")) {
+    int64_t mx = 0, long8 = 0, sum_long = 0;
+    for (size_t i = 0; i + 1 < P.fold_ptr.size(); i++) {
+      int64_t l = P.fold_ptr[i + 1] - P.fold_ptr[i];
+      mx = std::max(mx, l);
+      if (l > 8) {
+        long8++;
+        sum_long += l - 8;
+      }
+    }
+    fprintf(stderr, "[cfs_plan] fold: %zu destinations, longest list %lld, %lld lists > 8 (%lld entries beyond)\n",
+            P.fold_row.size(), (long long)mx, (long long)long8, (long long)sum_long);
+  }
   // ---- LDS window: the largest tile decides --------------------------------
   {
     int lds_slots = 64;
