@@ -165,11 +165,16 @@ def main():
             _lib.check(lib.cfs_hip_event_record(ev0[i], stream))
             A.spmv_phases(y, x, send, 1)
             _lib.check(lib.cfs_hip_event_record(ev1[i], stream))
-            A.spmv_phases(y, x, send, 2)
-        else:
+            if sh is None:
+                A.spmv_phases(y, x, send, 2)
+            else:
+                A.spmv_phases(y, x, send, 4)
+        elif sh is None:
             A.spmv_phases(y, x, send, 3)
+        else:
+            A.spmv_phases(y, x, send, 1 | 4)
         if sh is not None:
-            sh.exchange_and_fold(y)
+            sh.finish(y, x)   # exchange || local fold, then fold of what arrived
 
     def barrier():
         torch.cuda.synchronize()

@@ -564,7 +564,7 @@ struct DevBuf {
 struct cfs_hip_sym_s {
   int value_bytes = 8;
   virtual ~cfs_hip_sym_s() {}
-  virtual int spmv_local(void *y, const void *x, void *send, hipStream_t st, int phases = 3) = 0;
+  virtual int spmv_local(void *y, const void *x, void *send, hipStream_t st, int phases = 7) = 0;
   virtual int recv_fold(void *y, const void *recv, hipStream_t st) = 0;
   virtual int set_recv(int nrecv, const int *rows) = 0;
   virtual void stats(cfs_hip_sym_stats *o) = 0;
@@ -708,20 +708,17 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
       default: launch_tiles<1024>(y, x, st); break;
       }
     }
-    if (!(phases & CFS_HIP_PHASE_FOLD)) {
-      HIPCHK(hipGetLastError());
-      return 0;
-    }
-    if (nfold > 0)
-      hipLaunchKernelGGL((cfs_fold_kernel<V>), dim3((nfold + 255) / 256), dim3(256), 0,
-                         st, y, (const V *)strip.p, (const int32_t *)fold_row.p,
-                         (const int32_t *)fold_ptr.p, (const int32_t *)fold_idx.p, nfold);
-    if (nsend > 0) {
+    // pack first: the exchange of a shard can then start while the local fold runs
+    if ((phases & CFS_HIP_PHASE_PACK) && nsend > 0) {
       if (!sendv) return set_err(CFS_HIP_ERR_ARG, "shard has remote rows: send_buf required");
       hipLaunchKernelGGL((cfs_pack_kernel<V>), dim3((nsend + 255) / 256), dim3(256), 0,
                          st, (V *)sendv, (const V *)strip.p, (const int32_t *)send_ptr.p,
                          (const int32_t *)send_idx.p, nsend);
     }
+    if ((phases & CFS_HIP_PHASE_FOLD) && nfold > 0)
+      hipLaunchKernelGGL((cfs_fold_kernel<V>), dim3((nfold + 255) / 256), dim3(256), 0,
+                         st, y, (const V *)strip.p, (const int32_t *)fold_row.p,
+                         (const int32_t *)fold_ptr.p, (const int32_t *)fold_idx.p, nfold);
     HIPCHK(hipGetLastError());
     return 0;
   }

@@ -52,18 +52,25 @@ class ShardedSym:
         self.nsend, self.nrecv = int(send_rows.size), int(nrecv)
 
     def spmv(self, y_block, x):
-        """y_block <- rows [row_begin,row_end) of A x; x is the full vector."""
-        self.A.spmv_local(y_block, x, self.send_buf)
-        self.exchange_and_fold(y_block)
+        """y_block <- rows [row_begin,row_end) of A x; x is the full vector.
+        tile kernel -> pack -> [exchange || local fold] -> fold of what arrived"""
+        self.A.spmv_phases(y_block, x, self.send_buf, 1 | 4)   # tiles + pack
+        self.finish(y_block, x)
 
-    def exchange_and_fold(self, y_block):
-        """the one collective of the path + the owner-side sum (fixed order)"""
+    def finish(self, y_block, x):
+        """everything after tiles + pack: start the one collective of the path,
+        fold the local strips while it is in flight, then fold what arrived"""
         if self.stage:
             sh = self.send_buf[:self.nsend].cpu()
             rh = self.torch.zeros(self.nrecv, dtype=sh.dtype)
             self.dist.all_to_all_single(rh, sh, self.recv_splits, self.send_splits, group=self.pg)
             self.recv_buf[:self.nrecv].copy_(rh)
+            work = None
         else:
-            self.dist.all_to_all_single(self.recv_buf[:self.nrecv], self.send_buf[:self.nsend],
-                                        self.recv_splits, self.send_splits, group=self.pg)
+            work = self.dist.all_to_all_single(
+                self.recv_buf[:self.nrecv], self.send_buf[:self.nsend], self.recv_splits,
+                self.send_splits, group=self.pg, async_op=True)
+        self.A.spmv_phases(y_block, x, self.send_buf, 2)       # local fold
+        if work is not None:
+            work.wait()                                        # current stream waits for RCCL
         self.A.recv_fold(y_block, self.recv_buf)

@@ -189,7 +189,7 @@ class SymMatrix:
             _stream_ptr(stream)))
 
     def spmv_phases(self, y_block, x, send_buf, phases, stream=None):
-        """enqueue only the selected launches (1 = tile kernel, 2 = halo fold/pack)"""
+        """enqueue only the selected launches (1 = tile kernel, 2 = halo fold, 4 = pack)"""
         _lib.check(_lib.load().cfs_hip_sym_spmv_phases_async(
             self._h, _ptr(y_block), _ptr(x), _ptr(send_buf) if send_buf is not None else None,
             int(phases), _stream_ptr(stream)))

@@ -151,12 +151,16 @@ int cfs_hip_sym_spmv_local_async(cfs_hip_sym_t h, void *y_block_dev,
                                  void *stream);
 int cfs_hip_sym_recv_fold_async(cfs_hip_sym_t h, void *y_block_dev,
                                 const void *recv_buf_dev, void *stream);
-/* The SpMV of a handle is two launches: the tile kernel (streams the matrix;
- * the roofline kernel) and the halo fold (+ pack for shards).  This entry point
- * enqueues only the selected ones so that bench.py can bracket each with HIP
- * events; phases = CFS_HIP_PHASE_TILES | CFS_HIP_PHASE_FOLD is a full SpMV.   */
+/* The SpMV of a handle is two launches -- the tile kernel (streams the matrix;
+ * the roofline kernel) and the halo fold -- plus, for a shard, the pack of the
+ * contributions to lower ranks.  This entry point enqueues only the selected
+ * ones (in the order tiles, pack, fold) so that bench.py can bracket the tile
+ * kernel with HIP events and a shard can start its exchange before the local
+ * fold; CFS_HIP_PHASE_ALL is a full local SpMV.                               */
 #define CFS_HIP_PHASE_TILES 1
 #define CFS_HIP_PHASE_FOLD 2
+#define CFS_HIP_PHASE_PACK 4
+#define CFS_HIP_PHASE_ALL 7
 int cfs_hip_sym_spmv_phases_async(cfs_hip_sym_t h, void *y_block_dev,
                                   const void *x_dev, void *send_buf_dev,
                                   int phases, void *stream);

@@ -37,6 +37,12 @@ class HostShardDouble:
     def set_recv(self, rows):
         self.recv_rows = np.asarray(rows, dtype=np.int64)
 
+    def spmv_phases(self, y_block, x, send, phases):
+        # the double computes everything in the "tiles + pack" call; its local
+        # fold (phase 2 alone) has nothing left to do
+        if phases & 1:
+            self.spmv_local(y_block, x, send)
+
     def spmv_local(self, y_block, x, send):
         xn = x.numpy()
         rb, re = self.row_begin, self.row_end
