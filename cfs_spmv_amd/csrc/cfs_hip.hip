@@ -83,40 +83,39 @@ template <typename V> struct Pkt {
 __device__ __forceinline__ int leader_rank(unsigned long long leaders, int l) {
   return __popcll(leaders & (~0ull >> (63 - l))) - 1;
 }
-// The matrix stream is read exactly once per SpMV: the loads carry the
-// non-temporal hint so that they do not displace x, y, the slot tables and the
-// strips from L2 / Infinity Cache.
+// A matrix stream larger than the 256 MiB Infinity Cache is read exactly once
+// per SpMV: its loads then carry the non-temporal hint (NT) so that they do not
+// displace x, y, the slot tables and the strips from L2 / Infinity Cache
+// (measured: Flan stand-in 0.117 -> 0.110 ms).  A stream that FITS the cache
+// (ldoor, pwtk stand-ins) is served from it on every SpMV after the first and
+// must stay cacheable (ldoor: 0.049 ms plain vs 0.057 ms with NT).
 typedef double cfs_d2 __attribute__((ext_vector_type(2)));
 typedef float cfs_f4 __attribute__((ext_vector_type(4)));
 typedef unsigned short cfs_us4 __attribute__((ext_vector_type(4)));
-#ifndef CFS_NT_STREAM
-#define CFS_NT_STREAM 1
-#endif
-template <typename T> __device__ __forceinline__ T stream_load(const T *p) {
-#if CFS_NT_STREAM
-  return __builtin_nontemporal_load(p);
-#else
+template <bool NT, typename T> __device__ __forceinline__ T stream_load(const T *p) {
+  if (NT) return __builtin_nontemporal_load(p);
   return *p;
-#endif
 }
+template <bool NT>
 __device__ __forceinline__ void fetch_packet(Pkt<double> &p, const double *tv,
                                              const uint16_t *ts, uint32_t off, uint32_t soff,
                                              int cnt, unsigned long long leaders, int lane) {
   const int ll = min(lane, max(cnt, 1) - 1);
-  const cfs_d2 lo = stream_load(reinterpret_cast<const cfs_d2 *>(tv + off + ll * 2));
-  const cfs_d2 hi = stream_load(reinterpret_cast<const cfs_d2 *>(tv + off + 2 * cnt + ll * 2));
+  const cfs_d2 lo = stream_load<NT>(reinterpret_cast<const cfs_d2 *>(tv + off + ll * 2));
+  const cfs_d2 hi = stream_load<NT>(reinterpret_cast<const cfs_d2 *>(tv + off + 2 * cnt + ll * 2));
   const cfs_us4 c =
-      stream_load(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
+      stream_load<NT>(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
   p.c = make_ushort4(c.x, c.y, c.z, c.w);
   p.v[0] = lo.x; p.v[1] = lo.y; p.v[2] = hi.x; p.v[3] = hi.y;
 }
+template <bool NT>
 __device__ __forceinline__ void fetch_packet(Pkt<float> &p, const float *tv,
                                              const uint16_t *ts, uint32_t off, uint32_t soff,
                                              int cnt, unsigned long long leaders, int lane) {
   const int ll = min(lane, max(cnt, 1) - 1);
-  const cfs_f4 q = stream_load(reinterpret_cast<const cfs_f4 *>(tv + off + ll * 4));
+  const cfs_f4 q = stream_load<NT>(reinterpret_cast<const cfs_f4 *>(tv + off + ll * 4));
   const cfs_us4 c =
-      stream_load(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
+      stream_load<NT>(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
   p.c = make_ushort4(c.x, c.y, c.z, c.w);
   p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
 }
@@ -176,7 +175,7 @@ __device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigne
 // as a result path): 1 = no transposed LDS atomics, 2 = no LDS traffic at all,
 // 3 = windows only (no matrix stream), 4 = matrix stream only (no windows).
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int MODE>
+template <typename V, int BLOCK, int MODE, bool NT>
 __global__ void __launch_bounds__(BLOCK)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const int32_t *__restrict__ a_group_ptr,
                         const int32_t *__restrict__ a_slot_col,
@@ -283,11 +282,11 @@ __global__ void __launch_bounds__(BLOCK)
       meta_c = smeta[s];
       if (s_n < nsl) meta_n = smeta[s_n];
       const int p0 = s * 64 + lane, q0 = min(p0, nvr - 1);
-      const uint32_t i0 = stream_load(d.rowinfo + vrow0 + q0); // unconditional, clamped
-      const V d0 = stream_load(d.diag + vrow0 + q0);
+      const uint32_t i0 = stream_load<NT>(d.rowinfo + vrow0 + q0); // unconditional, clamped
+      const V d0 = stream_load<NT>(d.diag + vrow0 + q0);
       info_c = p0 < nvr ? i0 : 0u;
       dg_c = p0 < nvr ? d0 : V(0);
-      fetch_packet(N, tv, ts, meta_c.x, meta_c.y & 0x1ffffffu, (int)(meta_c.y >> 25),
+      fetch_packet<NT>(N, tv, ts, meta_c.x, meta_c.y & 0x1ffffffu, (int)(meta_c.y >> 25),
                    ((unsigned long long)meta_c.w << 32) | meta_c.z, lane);
     }
     const int ncp = (t.ncoo + 255) >> 8; // COO packets of this tile
@@ -296,10 +295,10 @@ __global__ void __launch_bounds__(BLOCK)
     C.v[0] = C.v[1] = C.v[2] = C.v[3] = V(0);
     C.c = Cr;
     if (wave < ncp) {
-      fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)wave * 256u,
+      fetch_packet<NT>(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)wave * 256u,
                    (uint32_t)wave * 256u, 64, ~0ull, lane);
       {
-        const cfs_us4 rr = stream_load(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + wave * 256 + lane * 4));
+        const cfs_us4 rr = stream_load<NT>(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + wave * 256 + lane * 4));
         Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
       }
     }
@@ -340,11 +339,11 @@ __global__ void __launch_bounds__(BLOCK)
       const bool have_next = s_n < nsl;
       if (have_next) { // next slice: header + head packet, a whole slice ahead
         const int pn = s_n * 64 + lane, qn = min(pn, nvr - 1);
-        const uint32_t in_ = stream_load(d.rowinfo + vrow0 + qn); // unconditional, clamped
-        const V dn = stream_load(d.diag + vrow0 + qn);
+        const uint32_t in_ = stream_load<NT>(d.rowinfo + vrow0 + qn); // unconditional, clamped
+        const V dn = stream_load<NT>(d.diag + vrow0 + qn);
         info_c = pn < nvr ? in_ : 0u;
         dg_c = pn < nvr ? dn : V(0);
-        fetch_packet(N, tv, ts, meta_n.x, meta_n.y & 0x1ffffffu, (int)(meta_n.y >> 25),
+        fetch_packet<NT>(N, tv, ts, meta_n.x, meta_n.y & 0x1ffffffu, (int)(meta_n.y >> 25),
                      ((unsigned long long)meta_n.w << 32) | meta_n.z, lane);
       }
       meta_c = meta_n;
@@ -364,11 +363,11 @@ __global__ void __launch_bounds__(BLOCK)
       while (g + 2 < amax) { // steady state: two packets per trip, no copies
         const int cnt1 = __popcll(__ballot(a > g + 1));
         const uint32_t off1 = off + 4u * (uint32_t)cnt, soff1 = soff + slot_block(leaders, cnt);
-        fetch_packet(B, tv, ts, off1, soff1, cnt1, leaders, lane);
+        fetch_packet<NT>(B, tv, ts, off1, soff1, cnt1, leaders, lane);
         if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
         const int cnt2 = __popcll(__ballot(a > g + 2));
         const uint32_t off2 = off1 + 4u * (uint32_t)cnt1, soff2 = soff1 + slot_block(leaders, cnt1);
-        fetch_packet(A, tv, ts, off2, soff2, cnt2, leaders, lane);
+        fetch_packet<NT>(A, tv, ts, off2, soff2, cnt2, leaders, lane);
         if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
         g += 2;
         off = off2;
@@ -377,7 +376,7 @@ __global__ void __launch_bounds__(BLOCK)
       }
       if (amax - g == 2) {
         const int cnt1 = __popcll(__ballot(a > g + 1));
-        fetch_packet(B, tv, ts, off + 4u * (uint32_t)cnt, soff + slot_block(leaders, cnt), cnt1,
+        fetch_packet<NT>(B, tv, ts, off + 4u * (uint32_t)cnt, soff + slot_block(leaders, cnt), cnt1,
                      leaders, lane);
         if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
         if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
@@ -392,9 +391,9 @@ __global__ void __launch_bounds__(BLOCK)
       const Pkt<V> Q = C;
       const ushort4 Qr = Cr;
       if (cp + NW < ncp) {
-        fetch_packet(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)(cp + NW) * 256u,
+        fetch_packet<NT>(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)(cp + NW) * 256u,
                      (uint32_t)(cp + NW) * 256u, 64, ~0ull, lane);
-        const cfs_us4 rr = stream_load(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + (cp + NW) * 256 + lane * 4));
+        const cfs_us4 rr = stream_load<NT>(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + (cp + NW) * 256 + lane * 4));
         Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
       }
       const int e0 = cp * 256 + lane * 4;
@@ -423,27 +422,30 @@ __global__ void __launch_bounds__(BLOCK)
   if (dbg && tid == 0) dbg[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
-// halo fold: y[dst] += sum of the strip entries aimed at dst, in a fixed order:
-// a lane sums the first 16 entries of its destination's list itself; what is
-// left of a long list (a hub row collects contributions from many tiles) is
-// summed by the whole wave, strided, with a fixed shuffle tree -- one slow lane
-// would otherwise decide the duration of the launch.
+// halo fold: y[dst] += sum of the strip entries aimed at dst, in a fixed order.
+// One 16-byte record per destination {dst, first strip entry, list offset, list
+// length}: the record, then y[dst] and the first entry in parallel -- two
+// dependent round trips for the common single-contribution destination.  A
+// lane sums the first 16 entries of its list itself; what is left of a long
+// list (a hub row collects contributions from many tiles) is summed by the
+// whole wave, strided, with a fixed shuffle tree -- one slow lane would
+// otherwise decide the duration of the launch.
 template <typename V>
 __global__ void __launch_bounds__(256)
     cfs_fold_kernel(V *__restrict__ y, const V *__restrict__ src,
-                    const int32_t *__restrict__ frow, const int32_t *__restrict__ fptr,
-                    const int32_t *__restrict__ fidx, int m) {
+                    const int4 *__restrict__ frec, const int32_t *__restrict__ fidx, int m) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int lane = threadIdx.x & 63;
   int r = 0, b = 0, e = 0;
   V s = V(0);
   if (i < m) {
-    r = frow[i];
-    b = fptr[i];
-    e = fptr[i + 1];
-    s = y[r];
+    const int4 rec = frec[i];
+    r = rec.x;
+    b = rec.z + 1; // entry 0 of the list is inlined in the record
+    e = rec.z + rec.w;
+    s = y[r] + src[rec.y];
   }
-  const int own_end = min(e, b + 16);
+  const int own_end = min(e, b + 15);
   for (int q = b; q < own_end; ++q) s += src[fidx[q]];
   unsigned long long need = __ballot(e > own_end);
   while (need) {
@@ -561,6 +563,16 @@ struct DevBuf {
   }
 };
 
+// {dst, first strip entry, list offset, list length} per fold destination
+static std::vector<int4> make_fold_records(const std::vector<int32_t> &dst,
+                                           const std::vector<int32_t> &ptr,
+                                           const std::vector<int32_t> &idx) {
+  std::vector<int4> rec(dst.size() + 1, make_int4(0, 0, 0, 0));
+  for (size_t i = 0; i < dst.size(); i++)
+    rec[i] = make_int4(dst[i], idx[ptr[i]], ptr[i], ptr[i + 1] - ptr[i]);
+  return rec;
+}
+
 struct cfs_hip_sym_s {
   int value_bytes = 8;
   virtual ~cfs_hip_sym_s() {}
@@ -581,11 +593,12 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   SymPlan<V> P; // big arrays released after upload
   DevBuf tiles, group_ptr, slot_col, rowinfo, diag, slice_meta, vals, slots, strip;
   DevBuf cvals, crows, ccols;
-  DevBuf fold_row, fold_ptr, fold_idx, send_ptr, send_idx;
-  DevBuf rfold_row, rfold_ptr, rfold_idx;
+  DevBuf fold_rec, fold_idx, send_ptr, send_idx;
+  DevBuf rfold_rec, rfold_idx;
   SymDev<V> dev{};
   int nfold = 0, nsend = 0, nrfold = 0;
   int ablate_mode = 0; // cfs_hip_options.flags & 7 (timing-only ablations)
+  bool nt_stream = true; // matrix stream larger than the Infinity Cache: non-temporal loads
   unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
   size_t lds_bytes = 0;
   int64_t halo_slots = 0, stream_len = 0, slot_len = 0, nslices = 0, coo_len = 0;
@@ -605,8 +618,10 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(ccols, P.ccols)
     UP(vals, P.vals)
     UP(slots, P.slots)
-    UP(fold_row, P.fold_dst)
-    UP(fold_ptr, P.fold_ptr)
+    {
+      std::vector<int4> rec = make_fold_records(P.fold_dst, P.fold_ptr, P.fold_idx);
+      if ((rc = fold_rec.upload(rec.data(), rec.size() * sizeof(int4)))) return rc;
+    }
     UP(fold_idx, P.fold_idx)
     UP(send_ptr, P.send_ptr)
     UP(send_idx, P.send_idx)
@@ -634,6 +649,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     dev.row_begin = P.row_begin;
     dev.lds_slots = P.lds_slots;
     lds_bytes = (size_t)P.lds_slots * (sizeof(V) + sizeof(double));
+    // the stream is cacheable across SpMVs only if it fits the 256 MiB Infinity Cache
+    nt_stream = (stream_len * (int64_t)sizeof(V) + slot_len * 2) > (int64_t)240 * 1024 * 1024;
     // release the big host arrays; keep the small metadata
     std::vector<V>().swap(P.vals);
     std::vector<uint16_t>().swap(P.slots);
@@ -647,17 +664,17 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     return raise_lds_limit();
   }
 
+  template <int BLOCK, int MODE, bool NT> int raise_attr() {
+    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, MODE, NT>,
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    return 0;
+  }
   template <int BLOCK> int raise_one() {
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 0>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 1>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 2>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 3>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 4>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    int rc;
+    if ((rc = raise_attr<BLOCK, 0, true>()) || (rc = raise_attr<BLOCK, 0, false>()) ||
+        (rc = raise_attr<BLOCK, 1, true>()) || (rc = raise_attr<BLOCK, 2, true>()) ||
+        (rc = raise_attr<BLOCK, 3, true>()) || (rc = raise_attr<BLOCK, 4, true>()))
+      return rc;
     return 0;
   }
   int raise_lds_limit() {
@@ -668,33 +685,22 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     }
   }
 
+  template <int BLOCK, int MODE, bool NT> void launch_one(V *y, const V *x, hipStream_t st) {
+    hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, MODE, NT>), dim3(P.ngroups), dim3(BLOCK),
+                       lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
+                       dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
+                       dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
+  }
   template <int BLOCK> void launch_tiles(V *y, const V *x, hipStream_t st) {
-    const int mode = ablate_mode;
-    if (mode == 1)
-      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 1>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
-                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
-    else if (mode == 2)
-      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 2>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
-                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
-    else if (mode == 3)
-      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 3>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
-                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
-    else if (mode == 4)
-      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 4>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
-                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
-    else
-      hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, 0>), dim3(P.ngroups), dim3(BLOCK),
-                         lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
-                         dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                         dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
+    switch (ablate_mode) {
+    case 1: launch_one<BLOCK, 1, true>(y, x, st); break;
+    case 2: launch_one<BLOCK, 2, true>(y, x, st); break;
+    case 3: launch_one<BLOCK, 3, true>(y, x, st); break;
+    case 4: launch_one<BLOCK, 4, true>(y, x, st); break;
+    default:
+      if (nt_stream) launch_one<BLOCK, 0, true>(y, x, st);
+      else launch_one<BLOCK, 0, false>(y, x, st);
+    }
   }
 
   int spmv_local(void *yv, const void *xv, void *sendv, hipStream_t st, int phases) override {
@@ -717,8 +723,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     }
     if ((phases & CFS_HIP_PHASE_FOLD) && nfold > 0)
       hipLaunchKernelGGL((cfs_fold_kernel<V>), dim3((nfold + 255) / 256), dim3(256), 0,
-                         st, y, (const V *)strip.p, (const int32_t *)fold_row.p,
-                         (const int32_t *)fold_ptr.p, (const int32_t *)fold_idx.p, nfold);
+                         st, y, (const V *)strip.p, (const int4 *)fold_rec.p,
+                         (const int32_t *)fold_idx.p, nfold);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -726,11 +732,12 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int set_recv(int nrecv, const int *rows) override {
     if (!cfs_plan::set_recv(P, nrecv, rows)) return set_err(CFS_HIP_ERR_ARG, P.error);
     int rc;
-    rfold_row = DevBuf();
-    rfold_ptr = DevBuf();
+    rfold_rec = DevBuf();
     rfold_idx = DevBuf();
-    if ((rc = rfold_row.upload(P.rfold_row.data(), P.rfold_row.size() * 4))) return rc;
-    if ((rc = rfold_ptr.upload(P.rfold_ptr.data(), P.rfold_ptr.size() * 4))) return rc;
+    {
+      std::vector<int4> rec = make_fold_records(P.rfold_row, P.rfold_ptr, P.rfold_idx);
+      if ((rc = rfold_rec.upload(rec.data(), rec.size() * sizeof(int4)))) return rc;
+    }
     if ((rc = rfold_idx.upload(P.rfold_idx.data(), P.rfold_idx.size() * 4))) return rc;
     nrfold = (int)P.rfold_row.size();
     return 0;
@@ -739,8 +746,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int recv_fold(void *yv, const void *recv, hipStream_t st) override {
     if (nrfold > 0)
       hipLaunchKernelGGL((cfs_fold_kernel<V>), dim3((nrfold + 255) / 256), dim3(256), 0,
-                         st, (V *)yv, (const V *)recv, (const int32_t *)rfold_row.p,
-                         (const int32_t *)rfold_ptr.p, (const int32_t *)rfold_idx.p, nrfold);
+                         st, (V *)yv, (const V *)recv, (const int4 *)rfold_rec.p,
+                         (const int32_t *)rfold_idx.p, nrfold);
     HIPCHK(hipGetLastError());
     return 0;
   }
@@ -771,7 +778,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
                         (int64_t)P.tiles.size() * (int64_t)sizeof(Tile);
     o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + slot_col.bytes +
                                 rowinfo.bytes + diag.bytes + slice_meta.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +
-                                slots.bytes + strip.bytes + fold_row.bytes + fold_ptr.bytes +
+                                slots.bytes + strip.bytes + fold_rec.bytes +
                                 fold_idx.bytes + send_ptr.bytes + send_idx.bytes);
   }
   const std::vector<int32_t> &send_counts() override { return P.send_counts; }
@@ -902,7 +909,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
 // resident wave of workgroups (a workgroup that has to wait for a slot would
 // run as a second round and double the launch time)
 template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
-  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0>;
+  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true>;
   HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k, BLOCK, lds));
   return 0;

@@ -51,6 +51,26 @@ class ShardedSym:
         self.recv_buf = torch.zeros(max(1, nrecv), dtype=tdt, device=device)
         self.nsend, self.nrecv = int(send_rows.size), int(nrecv)
 
+    def setup_allgather(self, row_splits):
+        """prepare y -> x all-gather (iterative solvers feed the product back as the
+        next input vector): equal-size padded blocks, one
+        all_gather_into_tensor"""
+        self.row_splits = [int(v) for v in row_splits]
+        self.max_rows = max(b - a for a, b in zip(self.row_splits[:-1], self.row_splits[1:]))
+        dt = self.send_buf.dtype
+        dev = self.torch.device("cpu") if self.stage else self.device
+        self._ag_in = self.torch.zeros(self.max_rows, dtype=dt, device=dev)
+        self._ag_out = self.torch.zeros(self.max_rows * self.nranks, dtype=dt, device=dev)
+
+    def allgather_rows(self, y_block, x_full):
+        """x_full[row_splits[r]:row_splits[r+1]] <- rank r's y_block, for every r"""
+        rows = y_block.numel()
+        self._ag_in[:rows].copy_(y_block)
+        self.dist.all_gather_into_tensor(self._ag_out, self._ag_in, group=self.pg)
+        for r in range(self.nranks):
+            a, b = self.row_splits[r], self.row_splits[r + 1]
+            x_full[a:b].copy_(self._ag_out[r * self.max_rows:r * self.max_rows + (b - a)])
+
     def spmv(self, y_block, x):
         """y_block <- rows [row_begin,row_end) of A x; x is the full vector.
         tile kernel -> pack -> [exchange || local fold] -> fold of what arrived"""

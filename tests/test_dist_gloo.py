@@ -78,7 +78,13 @@ def _worker(rank, world, port, name, scale, q):
         yb = torch.full((be.row_end - be.row_begin,), 7.0, dtype=torch.float64)
         for _ in range(2):  # twice: buffers are reused
             sh.spmv(yb, xt)
+        # y -> x all-gather (solver loop): every rank ends up with the whole product
+        sh.setup_allgather(rs)
+        full = torch.zeros(n, dtype=torch.float64)
+        sh.allgather_rows(yb, full)
         y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+        den_all = np.maximum(np.abs(y_ld), absrow)
+        assert float(np.max(np.abs(full.numpy() - y_ld) / den_all)) <= 1e-12
         sl = slice(be.row_begin, be.row_end)
         den = np.maximum(np.abs(y_ld[sl]), absrow[sl])
         err = float(np.max(np.abs(yb.numpy() - y_ld[sl]) / den)) if den.size else 0.0
