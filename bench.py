@@ -110,7 +110,15 @@ def main():
     lib = _lib.load()
     _lib.check(lib.cfs_hip_init(dev_index))
     dist = None
-    if N > 1:
+    # CFS_FORCE_DIST=1: rehearsal of the sharded code path (process group,
+    # all-to-all, owner-side fold) with a single rank on a single GPU
+    force_dist = N == 1 and os.environ.get("CFS_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if N > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -126,7 +134,7 @@ def main():
     opt = cfs.make_options(max_slots=args.max_slots, block_threads=args.block)
 
     t0 = time.time()
-    if N == 1:
+    if N == 1 and not force_dist:
         A = cfs.SymMatrix(n, rp, ci, va, options=opt)
         sh = None
     else:
