@@ -968,6 +968,64 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     delete m;
     return rc;
   }
+  // ---- XCD calibration (Tuning::Aggressive; CFS_HIP_FLAG_NO_CALIBRATE skips it) ----
+  // The eight XCDs do not stream at the same rate (measured: the groups dealt
+  // to XCD labels 4-6 finish ~7 % later than those of label 7, box after box)
+  // and the launch is as long as its slowest XCD.  Measure the mean finish time
+  // per XCD label with the timeline build of the kernel and re-cut the rows with
+  // per-XCD shares; keep the new schedule only if its launches end earlier.
+  if (!(opt && (opt->flags & CFS_HIP_FLAG_NO_CALIBRATE)) && m->P.ngroups >= 64 &&
+      m->P.nnz_low >= (int64_t)2000000) {
+    const int G = m->P.ngroups, nper = G >> 3;
+    DevBuf xb, yb;
+    if ((rc = xb.alloc((size_t)n * sizeof(V))) || (rc = yb.alloc((size_t)m->rows() * sizeof(V)))) {
+      delete m;
+      return rc;
+    }
+    HIPCHK(hipMemset(xb.p, 0x3f, xb.bytes)); // small positive values
+    std::vector<unsigned long long> st((size_t)G * 8);
+    auto measure = [&](SymMatrix<V> *h, double *xcd_end, double *kernel_end) -> int {
+      for (int k = 0; k < 8; k++) xcd_end[k] = 0;
+      *kernel_end = 0;
+      const int reps = 4;
+      for (int rep = 0; rep < reps; rep++) {
+        int ng = 0;
+        int r2 = h->timeline(yb.p, xb.p, st.data(), (int)st.size(), &ng);
+        if (r2) return r2;
+        unsigned long long t0 = ~0ull, t1 = 0;
+        for (int b = 0; b < G; b++) t0 = std::min(t0, st[(size_t)b * 8]);
+        for (int b = 0; b < G; b++) {
+          const double e = (double)(st[(size_t)b * 8 + 3] - t0);
+          xcd_end[b & 7] += e / (nper * reps);
+          t1 = std::max(t1, st[(size_t)b * 8 + 3]);
+        }
+        *kernel_end += (double)(t1 - t0) / reps;
+      }
+      return 0;
+    };
+    double e0[8], k0 = 0;
+    if (measure(m, e0, &k0) == 0) {
+      double mean = 0;
+      for (int k = 0; k < 8; k++) mean += e0[k] / 8;
+      po.force_order = m->P.perm.empty() ? 1 : 2;
+      po.group_share.assign(G, 1.0);
+      for (int g = 0; g < G; g++) po.group_share[g] = mean / e0[g / nper]; // slow XCD: less work
+      auto *nx = new SymMatrix<V>();
+      nx->value_bytes = (int)sizeof(V);
+      double e1[8], k1 = 0;
+      if (cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
+                                  nranks > 1 ? row_splits : nullptr, po, nx->P) &&
+          nx->P.ngroups == G && nx->upload() == 0 && measure(nx, e1, &k1) == 0 && k1 < k0) {
+        delete m;
+        m = nx;
+      } else {
+        delete nx;
+      }
+      if (getenv("CFS_PLAN_VERBOSE"))
+        fprintf(stderr, "[cfs_hip] XCD calibration: launch end %.1f us -> %.1f us (%s)\n", k0 / 100.0,
+                k1 / 100.0, k1 > 0 && k1 < k0 ? "kept" : "discarded");
+    }
+  }
   m->ablate_mode = opt ? (opt->flags & CFS_HIP_FLAG_ABLATE_MASK) : 0;
   *out = m;
   return 0;

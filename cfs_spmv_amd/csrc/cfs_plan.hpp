@@ -50,10 +50,10 @@ struct Options {
   bool reorder = true; // cluster rows so that tiles are compact in every direction
   int force_order = 0; // 0 = pick the order with fewer halo slots, 1 = natural, 2 = clustered
   // relative work share of every persistent group (size = number of groups,
-  // any positive scale); empty = equal shares.  (Measured on MI355X: re-cutting
-  // the shares from per-workgroup finish times does not shorten the launch --
-  // workgroups of one CU finish in dispatch order whatever their shares, the
-  // CU total is what counts -- so nothing sets this today.)
+  // any positive scale); empty = equal shares.  The creator's XCD calibration
+  // fills it with one value per XCD: the eight XCDs do not stream at equal rates.
+  // (Per-GROUP shares from per-workgroup finish times do not help: workgroups of
+  // one CU finish in dispatch order whatever their shares, the CU total counts.)
   std::vector<double> group_share;
   int wg_per_cu = 0; // measured residency of the tile kernel (0 = estimate)
   int num_cus = 0;   // compute units of the device (0 = 256, MI355X)

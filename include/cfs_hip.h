@@ -84,6 +84,10 @@ typedef struct {
 #define CFS_HIP_FLAG_NO_REORDER 8
 /* always keep the clustered order (skip the halo-count comparison)            */
 #define CFS_HIP_FLAG_FORCE_CLUSTER 16
+/* tune() measures the per-XCD finish times of a few launches and re-cuts the
+ * rows with per-XCD work shares (kept only if the launches end earlier; only
+ * for matrices with >= 2M stored nonzeros).  This flag skips that step.       */
+#define CFS_HIP_FLAG_NO_CALIBRATE 32
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->
