@@ -51,6 +51,7 @@ static int ensure_init() {
 // ---------------------------------------------------------------------------
 template <typename V> struct SymDev {
   const Tile *tiles;
+  const Tile *gfirst;
   const int32_t *group_ptr;
   const int32_t *slot_col; // original column of every slot of every tile
   const uint32_t *rowinfo;
@@ -177,7 +178,8 @@ __device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigne
 // ---------------------------------------------------------------------------
 template <typename V, int BLOCK, int MODE, bool NT>
 __global__ void __launch_bounds__(BLOCK)
-    cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const int32_t *__restrict__ a_group_ptr,
+    cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const Tile *__restrict__ a_gfirst,
+                        const int32_t *__restrict__ a_group_ptr,
                         const int32_t *__restrict__ a_slot_col,
                         const uint32_t *__restrict__ a_rowinfo, const V *__restrict__ a_diag,
                         const uint4 *__restrict__ a_slice_meta, const V *__restrict__ a_vals,
@@ -192,6 +194,7 @@ __global__ void __launch_bounds__(BLOCK)
   // memory counter the matrix stream is pipelined on
   struct {
     const Tile *__restrict__ tiles;
+    const Tile *__restrict__ gfirst;
     const int32_t *__restrict__ group_ptr;
     const int32_t *__restrict__ slot_col;
     const uint32_t *__restrict__ rowinfo;
@@ -204,7 +207,7 @@ __global__ void __launch_bounds__(BLOCK)
     const uint16_t *__restrict__ ccols;
     V *__restrict__ strip;
     int row_begin, lds_slots;
-  } d = {a_tiles, a_group_ptr, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_vals,
+  } d = {a_tiles, a_gfirst, a_group_ptr, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_vals,
          a_slots, a_cvals, a_crows, a_ccols, a_strip, a_row_begin, a_lds_slots};
   // slice ticket counter of the current tile (16 B so the dynamic region below
   // stays 16-byte aligned)
@@ -253,11 +256,14 @@ __global__ void __launch_bounds__(BLOCK)
       for (int k = 0; k < U; ++k) xr[k] = V(idx[k]);
     }
   };
-  if (t0 < t1) gather_x(d.tiles[t0]);
+  // the group's first tile comes from a per-group copy: its descriptor does not
+  // wait for group_ptr (one dependent round trip less before the first x gather)
+  const Tile tfirst = d.gfirst[g];
+  if (t0 < t1) gather_x(tfirst);
   int prev_nown = 0, prev_nslots = 0, prev_slot_off = 0, prev_halo_off = 0;
 
   for (int ti = t0; ti < t1; ++ti) {
-    const Tile t = d.tiles[ti];
+    const Tile t = ti == t0 ? tfirst : d.tiles[ti];
     const int nown = t.nown, nslots = t.nslots;
     const int vrow0 = t.vrow_off, nvr = t.nvrows;
     const V *tv = d.vals + t.nnz_off;
@@ -591,7 +597,7 @@ struct cfs_hip_sym_s {
 
 template <typename V> struct SymMatrix : cfs_hip_sym_s {
   SymPlan<V> P; // big arrays released after upload
-  DevBuf tiles, group_ptr, slot_col, rowinfo, diag, slice_meta, vals, slots, strip;
+  DevBuf tiles, gfirst, group_ptr, slot_col, rowinfo, diag, slice_meta, vals, slots, strip;
   DevBuf cvals, crows, ccols;
   DevBuf fold_rec, fold_idx, send_ptr, send_idx;
   DevBuf rfold_rec, rfold_idx;
@@ -608,6 +614,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
 #define UP(buf, vec)                                                          \
   if ((rc = buf.upload(vec.data(), vec.size() * sizeof(vec[0])))) return rc;
     UP(tiles, P.tiles)
+    UP(gfirst, P.group_first)
     UP(group_ptr, P.group_ptr)
     UP(slot_col, P.slot_col)
     UP(rowinfo, P.rowinfo)
@@ -635,6 +642,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     nfold = (int)P.fold_dst.size();
     nsend = (int)P.send_row.size();
     dev.tiles = (const Tile *)tiles.p;
+    dev.gfirst = (const Tile *)gfirst.p;
     dev.group_ptr = (const int32_t *)group_ptr.p;
     dev.slot_col = (const int32_t *)slot_col.p;
     dev.rowinfo = (const uint32_t *)rowinfo.p;
@@ -687,7 +695,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
 
   template <int BLOCK, int MODE, bool NT> void launch_one(V *y, const V *x, hipStream_t st) {
     hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, MODE, NT>), dim3(P.ngroups), dim3(BLOCK),
-                       lds_bytes, st, dev.tiles, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
+                       lds_bytes, st, dev.tiles, dev.gfirst, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                        dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
                        dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
   }

@@ -103,6 +103,8 @@ template <typename V> struct SymPlan {
   // schedule
   std::vector<Tile> tiles;
   std::vector<int32_t> group_ptr;   // [ngroups+1] tiles of persistent group g
+  std::vector<Tile> group_first;    // [ngroups] copy of each group's first tile: one
+                                    // dependent load less at kernel start
   std::vector<int32_t> halo_col;    // [H] column of every halo slot (schedule space)
   std::vector<int32_t> slot_col;    // [sum nslots + 1] ORIGINAL column of every slot
   std::vector<int32_t> perm;        // [rows] schedule row -> original row (empty = identity)
@@ -727,6 +729,10 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     for (auto &t : P.tiles) lds_slots = std::max(lds_slots, (int)t.nslots);
     P.lds_slots = (lds_slots + 63) / 64 * 64;
   }
+
+  P.group_first.assign(P.ngroups, Tile{});
+  for (int g = 0; g < P.ngroups; g++)
+    if (P.group_ptr[g] < P.group_ptr[g + 1]) P.group_first[g] = P.tiles[P.group_ptr[g]];
 
   // ---- schedule space -> original indices -------------------------------------
   // the kernels address x and y in the caller's (original) numbering
