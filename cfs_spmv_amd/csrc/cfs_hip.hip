@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(BLOCK)
   // while the y window is flushed.
   constexpr int U = cfs_plan::kSlotsPerThread;
   V xr[U];
+  bool first_gather = true;
   auto gather_x = [&](const Tile &tn) {
     // every load is unconditional (clamped index): a load under a divergent
     // branch would make the compiler drain vmcnt before the other side of the
@@ -247,6 +248,10 @@ __global__ void __launch_bounds__(BLOCK)
     for (int k = 0; k < U; ++k) {
       const int i = min(tid + k * BLOCK, tn.nslots - 1);
       idx[k] = d.slot_col[tn.slot_off + i]; // slot_col is padded by one entry
+    }
+    if (dbg && tid == 0 && first_gather) { // diagnostic: when did the slot table arrive?
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      dbg[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
     }
     if (MODE != 4) {
 #pragma unroll
@@ -259,8 +264,13 @@ __global__ void __launch_bounds__(BLOCK)
   // the group's first tile comes from a per-group copy: its descriptor does not
   // wait for group_ptr (one dependent round trip less before the first x gather)
   const Tile tfirst = d.gfirst[g];
+  if (dbg && tid == 0) dbg[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime() + (tfirst.nown & 0);
   if (t0 < t1) gather_x(tfirst);
-  int prev_nown = 0, prev_nslots = 0, prev_slot_off = 0, prev_halo_off = 0;
+  first_gather = false;
+  if (dbg && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    dbg[blockIdx.x * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+  }
 
   for (int ti = t0; ti < t1; ++ti) {
     const Tile t = ti == t0 ? tfirst : d.tiles[ti];
@@ -271,9 +281,20 @@ __global__ void __launch_bounds__(BLOCK)
     const uint4 *smeta = d.slice_meta + t.slice_base;
     const int nsl = t.nslices;
 
-    // the matrix stream does not depend on x: request this wave's first slice
-    // header and head packet (and its first COO packet) before touching the LDS
-    // windows.  Slices are handed out dynamically (they are sorted by cost, so
+    // fill both LDS windows.  A thread owns the same slot indices here and in the
+    // flush at the end of the previous tile, so no barrier is needed between.
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+      const int i = tid + k * BLOCK;
+      if (i < nslots) {
+        xl[i] = xr[k];
+        yl[i] = 0.0;
+      }
+    }
+    // the matrix stream does not depend on x: this wave's first slice header and
+    // head packet (and its first COO packet) are requested BEFORE the barrier --
+    // but after the window fill, so that the fill (and with it the barrier) waits
+    // for the x gather only and not for these HBM loads.  Slices are handed out dynamically (they are sorted by cost, so
     // this is longest-first scheduling over the waves): a wave starts with
     // slices `wave` and `wave + NW` and draws every later one from an LDS
     // ticket counter one slice ahead of its use.
@@ -306,24 +327,6 @@ __global__ void __launch_bounds__(BLOCK)
       {
         const cfs_us4 rr = stream_load<NT>(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + wave * 256 + lane * 4));
         Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
-      }
-    }
-    // flush the previous tile's y window and refill both windows.  A thread
-    // owns the same slot indices in both steps, so no barrier is needed between.
-    int yidx[U];
-#pragma unroll
-    for (int k = 0; k < U; ++k) // own rows' y positions (original numbering, block-local)
-      yidx[k] = d.slot_col[prev_slot_off + min(tid + k * BLOCK, max(prev_nown - 1, 0))] - d.row_begin;
-#pragma unroll
-    for (int k = 0; k < U; ++k) {
-      const int i = tid + k * BLOCK;
-      if (MODE != 4) {
-        if (i < prev_nown) y[yidx[k]] = (V)yl[i];
-        else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = (V)yl[i];
-      }
-      if (i < nslots) {
-        xl[i] = xr[k];
-        yl[i] = 0.0;
       }
     }
     if (tid == 0) cfs_ticket[0] = 2 * NW;
@@ -408,22 +411,26 @@ __global__ void __launch_bounds__(BLOCK)
       if (e0 + 2 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[2], Qr.z, Q.c.z);
       if (e0 + 3 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[3], Qr.w, Q.c.w);
     }
-    if (dbg && lane == 0 && ti + 1 == t1) dbg[blockIdx.x * 8 + 4 + min(wave, 3)] = __builtin_amdgcn_s_memrealtime();
+    if (dbg && lane == 0 && wave == 0 && ti + 1 == t1) dbg[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     if (ti + 1 < t1) gather_x(d.tiles[ti + 1]); // lands behind the barrier + flush
-    prev_nown = nown;
-    prev_nslots = nslots;
-    prev_slot_off = t.slot_off;
-    prev_halo_off = t.halo_off;
-    __syncthreads();
-  }
-  if (dbg && tid == 0) dbg[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-  // flush the last tile
+    // y positions of the own rows (original numbering, block-local): requested
+    // before the barrier, used by the flush after it
+    int yidx[U];
 #pragma unroll
-  for (int k = 0; k < U; ++k) {
-    const int i = tid + k * BLOCK;
-    if (MODE == 4) break;
-    if (i < prev_nown) y[d.slot_col[prev_slot_off + i] - d.row_begin] = (V)yl[i];
-    else if (i < prev_nslots) d.strip[prev_halo_off + (i - prev_nown)] = (V)yl[i];
+    for (int k = 0; k < U; ++k)
+      yidx[k] = d.slot_col[t.slot_off + min(tid + k * BLOCK, nown - 1)] - d.row_begin;
+    __syncthreads();
+    if (dbg && tid == 0 && ti + 1 == t1) dbg[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+    // flush the y window: own rows -> y, halo sums -> this tile's strip.  Plain
+    // stores; y is fully overwritten.
+    if (MODE != 4) {
+#pragma unroll
+      for (int k = 0; k < U; ++k) {
+        const int i = tid + k * BLOCK;
+        if (i < nown) y[yidx[k]] = (V)yl[i];
+        else if (i < nslots) d.strip[t.halo_off + (i - nown)] = (V)yl[i];
+      }
+    }
   }
   if (dbg && tid == 0) dbg[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
 }

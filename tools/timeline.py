@@ -31,9 +31,9 @@ for cfg in cfgs:
     print("  x ready    ", q(us[:, 1]))
     print("  slices done", q(us[:, 2]))
     print("  end        ", q(us[:, 3]))
-    w = us[:, 4:8]
-    print("  wave spread at last tile end (max-min per WG)", q(w.max(1) - w.min(1)))
-    print("  first wave done", q(w.min(1)), "| last wave done", q(w.max(1)))
+    print("  tile desc   ", q(us[:, 4]))
+    print("  slot table  ", q(us[:, 5]))
+    print("  x gathered  ", q(us[:, 6]))
     end = us[:, 3]; dur = us[:, 3] - us[:, 1]
     shift = 0
     nper = ng.value // 8
