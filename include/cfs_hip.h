@@ -193,8 +193,10 @@ typedef struct {
 int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out);
 /* developer diagnostic: one extra launch of the tile kernel that records, per
  * persistent workgroup (in blockIdx order), 8 words of 100 MHz wall-clock
- * stamps: [0] start, [1] first x window ready, [2] slices done, [3] end,
- * [4..7] end of the last tile's slices for waves 0..3.  Not used by any product
+ * stamps: [0] start, [1] first x window ready (after the barrier), [2] slices
+ * of the last tile done, [3] end, [4] first tile descriptor loaded, [5] slot
+ * table of the first tile arrived (thread 0), [6] its x values arrived
+ * (thread 0), [7] wave 0 finished its last slice.  Not used by any product
  * path; tools/timeline.py reads it.                                          */
 int cfs_hip_sym_debug_timeline(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
                                unsigned long long *stamps, int capacity_words,
