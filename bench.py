@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loops", type=int, default=32)
+    ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "reduce_scatter"],
+                    help="N>1: sparse all-to-all of the touched rows (default) or the dense "
+                         "reduce-scatter of padded blocks")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the tile kernel with HIP events on every n-th timed step")
     return ap.parse_args()
@@ -141,7 +144,8 @@ def main():
         from cfs_spmv_amd.dist import ShardedSym
         rs = cfs.balanced_splits(n, rp, ci, N)
         A = cfs.SymMatrix(n, rp, ci, va, options=opt, row_splits=rs, rank=rank)
-        sh = ShardedSym(A, N, rank, np_dt, dev, stage_via_host=(backend != "nccl"))
+        sh = ShardedSym(A, N, rank, np_dt, dev, stage_via_host=(backend != "nccl"),
+                        exchange=args.exchange, row_splits=rs)
     preproc = time.time() - t0
     st = A.stats()
     rows = st["row_end"] - st["row_begin"]
@@ -257,6 +261,7 @@ def main():
                             f"scale {args.scale}: n={n}, nnz_full={nnz_full}, "
                             f"nnz_low={nnz_low}, symmetric SSS SpMV y=Ax",
                 "format": "sss", "sharding": f"1d-row-blocks x{N}",
+                "exchange": args.exchange if N > 1 else None,
                 "algorithmic_bytes_per_spmv": int(nnz_low * (4 + va.itemsize)
                                                   + n * (4 + 3 * va.itemsize)),
                 "effective_GBps_whole_step": round(

@@ -21,7 +21,8 @@ class ShardedSym:
     spmv_local(y_block, x, send), recv_fold(y_block, recv), row_begin, row_end.
     On a GPU box that is cfs_spmv_amd.SymMatrix; CPU tests pass a double."""
 
-    def __init__(self, backend, nranks, rank, dtype, device, pg=None, stage_via_host=False):
+    def __init__(self, backend, nranks, rank, dtype, device, pg=None, stage_via_host=False,
+                 exchange="all_to_all", row_splits=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -50,6 +51,24 @@ class ShardedSym:
         self.send_buf = torch.zeros(max(1, send_rows.size), dtype=tdt, device=device)
         self.recv_buf = torch.zeros(max(1, nrecv), dtype=tdt, device=device)
         self.nsend, self.nrecv = int(send_rows.size), int(nrecv)
+        # exchange = "reduce_scatter": the dense form the north-star names -- every
+        # rank scatters its packed contributions into a zero vector of nranks
+        # equal (padded) blocks and ONE reduce-scatter(sum) hands each owner the sum
+        # for its block.  Moves nranks*max_rows values per rank instead of the few
+        # touched rows, so it is the slower option; kept selectable.
+        self.exchange = exchange
+        if exchange == "reduce_scatter":
+            if row_splits is None:
+                raise ValueError("reduce_scatter exchange needs row_splits")
+            rs = np.asarray(row_splits, dtype=np.int64)
+            self.rs_max_rows = int(np.max(np.diff(rs)))
+            owner = np.searchsorted(rs, send_rows, side="right") - 1
+            pos = owner * self.rs_max_rows + (send_rows - rs[owner])
+            self.rs_pos = torch.from_numpy(pos.astype(np.int64)).to(device)
+            self.rs_dense = torch.zeros(self.rs_max_rows * nranks, dtype=tdt, device=device)
+            self.rs_out = torch.zeros(self.rs_max_rows, dtype=tdt, device=device)
+        elif exchange != "all_to_all":
+            raise ValueError(f"unknown exchange {exchange!r}")
 
     def setup_allgather(self, row_splits):
         """prepare y -> x all-gather (iterative solvers feed the product back as the
@@ -80,6 +99,8 @@ class ShardedSym:
     def finish(self, y_block, x):
         """everything after tiles + pack: start the one collective of the path,
         fold the local strips while it is in flight, then fold what arrived"""
+        if self.exchange == "reduce_scatter":
+            return self._finish_reduce_scatter(y_block, x)
         if self.stage:
             sh = self.send_buf[:self.nsend].cpu()
             rh = self.torch.zeros(self.nrecv, dtype=sh.dtype)
@@ -94,3 +115,23 @@ class ShardedSym:
         if work is not None:
             work.wait()                                        # current stream waits for RCCL
         self.A.recv_fold(y_block, self.recv_buf)
+
+    def _finish_reduce_scatter(self, y_block, x):
+        torch, dist = self.torch, self.dist
+        self.rs_dense.zero_()
+        if self.nsend:
+            self.rs_dense.index_copy_(0, self.rs_pos, self.send_buf[:self.nsend])
+        backend = dist.get_backend(self.pg)
+        if backend == "gloo" or self.stage:  # CPU rehearsal: gloo has no reduce_scatter_tensor
+            tmp = self.rs_dense.cpu()
+            dist.all_reduce(tmp, group=self.pg)
+            out = tmp[self.rank * self.rs_max_rows:(self.rank + 1) * self.rs_max_rows]
+            self.rs_out.copy_(out)
+            work = None
+        else:
+            work = dist.reduce_scatter_tensor(self.rs_out, self.rs_dense, group=self.pg,
+                                              async_op=True)
+        self.A.spmv_phases(y_block, x, self.send_buf, 2)       # local fold
+        if work is not None:
+            work.wait()
+        y_block += self.rs_out[:y_block.numel()]

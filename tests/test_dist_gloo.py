@@ -58,7 +58,7 @@ class HostShardDouble:
                       recv.numpy()[:self.recv_rows.size])
 
 
-def _worker(rank, world, port, name, scale, q):
+def _worker(rank, world, port, name, scale, q, exchange="all_to_all"):
     try:
         sys.path.insert(0, ROOT)
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -73,7 +73,8 @@ def _worker(rank, world, port, name, scale, q):
         x = synth.make_x(n)
         rs = cfs.balanced_splits(n, rp, ci, world)
         be = HostShardDouble(n, rp, ci, va, world, rank, rs)
-        sh = ShardedSym(be, world, rank, np.float64, torch.device("cpu"))
+        sh = ShardedSym(be, world, rank, np.float64, torch.device("cpu"), exchange=exchange,
+                        row_splits=rs)
         xt = torch.from_numpy(x.copy())
         yb = torch.full((be.row_end - be.row_begin,), 7.0, dtype=torch.float64)
         for _ in range(2):  # twice: buffers are reused
@@ -99,9 +100,10 @@ def _worker(rank, world, port, name, scale, q):
         q.put((rank, f"{e}\n{traceback.format_exc()}", False, 0, 0))
 
 
-@pytest.mark.parametrize("world,name,scale", [(2, "Flan_1565", 0.01), (3, "pwtk", 0.03),
-                                              (2, "ldoor", 0.01)])
-def test_sharded_exchange_gloo(world, name, scale):
+@pytest.mark.parametrize("world,name,scale,exchange", [
+    (2, "Flan_1565", 0.01, "all_to_all"), (3, "pwtk", 0.03, "all_to_all"),
+    (2, "ldoor", 0.01, "all_to_all"), (3, "Flan_1565", 0.01, "reduce_scatter")])
+def test_sharded_exchange_gloo(world, name, scale, exchange):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -109,7 +111,7 @@ def test_sharded_exchange_gloo(world, name, scale):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, name, scale, q))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, name, scale, q, exchange))
              for r in range(world)]
     for p in procs:
         p.start()
