@@ -436,13 +436,15 @@ __global__ void __launch_bounds__(BLOCK)
 }
 
 // halo fold: y[dst] += sum of the strip entries aimed at dst, in a fixed order.
-// One 16-byte record per destination {dst, first strip entry, list offset, list
-// length}: the record, then y[dst] and the first entry in parallel -- two
-// dependent round trips for the common single-contribution destination.  A
-// lane sums the first 16 entries of its list itself; what is left of a long
-// list (a hub row collects contributions from many tiles) is summed by the
-// whole wave, strided, with a fixed shuffle tree -- one slow lane would
-// otherwise decide the duration of the launch.
+// One 16-byte record per destination {dst, e0, e1, e2}: up to three strip entries
+// are inlined (e1 / e2 = -1 when absent), so the common destination costs two
+// dependent round trips: the record, then y[dst] and its entries all in flight
+// together.  A longer list keeps e0, e1 in the record and e2 = -(offset + 2) of
+// its remainder in `fidx`: [count, entry 2, entry 3, ...].  A lane sums the next
+// 16 entries itself, four loads in flight at a time; what is left of a very long
+// list (a hub row collects contributions from many tiles) is summed by the whole
+// wave, strided, with a fixed shuffle tree -- one slow lane would otherwise
+// decide the duration of the launch.  The order of the additions is fixed.
 template <typename V>
 __global__ void __launch_bounds__(256)
     cfs_fold_kernel(V *__restrict__ y, const V *__restrict__ src,
@@ -454,12 +456,31 @@ __global__ void __launch_bounds__(256)
   if (i < m) {
     const int4 rec = frec[i];
     r = rec.x;
-    b = rec.z + 1; // entry 0 of the list is inlined in the record
-    e = rec.z + rec.w;
-    s = y[r] + src[rec.y];
+    const V y0 = y[r];
+    const V s0 = src[rec.y];
+    const V s1 = src[max(rec.z, 0)]; // unconditional, clamped: all in flight together
+    const V s2 = src[max(rec.w, 0)];
+    s = y0 + s0;
+    if (rec.z >= 0) s += s1;
+    if (rec.w >= 0) s += s2;
+    if (rec.w < -1) {
+      b = -(rec.w + 2);
+      e = b + 1 + fidx[b];
+      b += 1;
+    }
   }
-  const int own_end = min(e, b + 15);
-  for (int q = b; q < own_end; ++q) s += src[fidx[q]];
+  const int own_end = min(e, b + 16);
+  for (int q = b; q < own_end; q += 4) {
+    int j[4];
+    V v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) j[u] = fidx[min(q + u, own_end - 1)];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = src[j[u]];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (q + u < own_end) s += v[u];
+  }
   unsigned long long need = __ballot(e > own_end);
   while (need) {
     const int L = __ffsll((long long)need) - 1;
@@ -576,14 +597,24 @@ struct DevBuf {
   }
 };
 
-// {dst, first strip entry, list offset, list length} per fold destination
-static std::vector<int4> make_fold_records(const std::vector<int32_t> &dst,
-                                           const std::vector<int32_t> &ptr,
-                                           const std::vector<int32_t> &idx) {
-  std::vector<int4> rec(dst.size() + 1, make_int4(0, 0, 0, 0));
-  for (size_t i = 0; i < dst.size(); i++)
-    rec[i] = make_int4(dst[i], idx[ptr[i]], ptr[i], ptr[i + 1] - ptr[i]);
-  return rec;
+// fold records {dst, e0, e1, e2 | -(offset + 2)} and the remainder lists
+// [count, entries 2..] of destinations with more than three contributions
+// (see cfs_fold_kernel)
+static void make_fold_records(const std::vector<int32_t> &dst, const std::vector<int32_t> &ptr,
+                              const std::vector<int32_t> &idx, std::vector<int4> &rec,
+                              std::vector<int32_t> &rest) {
+  rec.assign(dst.size() + 1, make_int4(0, 0, -1, -1));
+  rest.clear();
+  for (size_t i = 0; i < dst.size(); i++) {
+    const int b = ptr[i], len = ptr[i + 1] - ptr[i];
+    int4 r = make_int4(dst[i], idx[b], len > 1 ? idx[b + 1] : -1, len == 3 ? idx[b + 2] : -1);
+    if (len > 3) {
+      r.w = -((int)rest.size() + 2);
+      rest.push_back(len - 2);
+      rest.insert(rest.end(), idx.begin() + b + 2, idx.begin() + b + len);
+    }
+    rec[i] = r;
+  }
 }
 
 struct cfs_hip_sym_s {
@@ -633,10 +664,12 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(vals, P.vals)
     UP(slots, P.slots)
     {
-      std::vector<int4> rec = make_fold_records(P.fold_dst, P.fold_ptr, P.fold_idx);
+      std::vector<int4> rec;
+      std::vector<int32_t> rest;
+      make_fold_records(P.fold_dst, P.fold_ptr, P.fold_idx, rec, rest);
       if ((rc = fold_rec.upload(rec.data(), rec.size() * sizeof(int4)))) return rc;
+      if ((rc = fold_idx.upload(rest.data(), rest.size() * 4))) return rc;
     }
-    UP(fold_idx, P.fold_idx)
     UP(send_ptr, P.send_ptr)
     UP(send_idx, P.send_idx)
 #undef UP
@@ -750,10 +783,12 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     rfold_rec = DevBuf();
     rfold_idx = DevBuf();
     {
-      std::vector<int4> rec = make_fold_records(P.rfold_row, P.rfold_ptr, P.rfold_idx);
+      std::vector<int4> rec;
+      std::vector<int32_t> rest;
+      make_fold_records(P.rfold_row, P.rfold_ptr, P.rfold_idx, rec, rest);
       if ((rc = rfold_rec.upload(rec.data(), rec.size() * sizeof(int4)))) return rc;
+      if ((rc = rfold_idx.upload(rest.data(), rest.size() * 4))) return rc;
     }
-    if ((rc = rfold_idx.upload(P.rfold_idx.data(), P.rfold_idx.size() * 4))) return rc;
     nrfold = (int)P.rfold_row.size();
     return 0;
   }
@@ -915,6 +950,12 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     r.flags = o->flags;
     r.reorder = !(o->flags & CFS_HIP_FLAG_NO_REORDER);
     if (o->flags & CFS_HIP_FLAG_FORCE_CLUSTER) r.force_order = 2;
+  }
+  // tuning knob for callers that cannot pass options (the C++ surface): LDS slots
+  // per tile, like CFS_NUM_THREADS for the reference's partitions
+  if (r.max_slots <= 0) {
+    const char *e = getenv("CFS_HIP_MAX_SLOTS");
+    if (e && atoi(e) > 0) r.max_slots = atoi(e);
   }
   return r;
 }

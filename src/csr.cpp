@@ -104,7 +104,8 @@ bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning) {
   if (tuned_) return true;
   static_assert(std::is_same<IndexT, int>::value, "int indices only (src/csr.cpp:10-11)");
   int rc;
-  if (symmetric_) {
+  bool use_sss = symmetric_;
+  if (use_sss) {
 #ifdef _LOG_INFO
     std::cout << "[INFO]: compressing for symmetry: MI355X tile schedule" << std::endl;
 #endif
@@ -113,10 +114,22 @@ bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning) {
       rc = cfs_hip_sym_create_f64(nrows_, rowptr_, colind_, (const double *)values_, nullptr, &h);
     else
       rc = cfs_hip_sym_create_f32(nrows_, rowptr_, colind_, (const float *)values_, nullptr, &h);
-    if (rc != 0) fatal(std::string("tune() failed: ") + cfs_hip_last_error());
-    sym_handle_ = h;
+    if (rc == CFS_HIP_ERR_UNSUPPORTED) {
+      // a row with more stored columns than an LDS window holds: the symmetric
+      // schedule does not apply; the full CSR is still here, so the general HIP
+      // kernel computes the same product (slower, never wrong)
+      std::cout << "[INFO]: " << cfs_hip_last_error()
+                << " -- falling back to the general CSR kernel on the GPU" << std::endl;
+      use_sss = false;
+    } else if (rc != 0) {
+      fatal(std::string("tune() failed: ") + cfs_hip_last_error());
+    } else {
+      sym_handle_ = h;
+    }
+  }
+  if (use_sss) {
     cfs_hip_sym_stats st;
-    cfs_hip_sym_get_stats(h, &st);
+    cfs_hip_sym_get_stats((cfs_hip_sym_t)sym_handle_, &st);
     device_bytes_ = (size_t)st.device_bytes;
 #ifdef _LOG_INFO
     std::cout << "[INFO]: " << st.ntiles << " tiles, " << st.halo_slots << " halo slots, "

@@ -115,6 +115,28 @@ def test_drivers_end_to_end(tmp_path):
     assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.gpu
+def test_unschedulable_symmetric_matrix_falls_back_to_gpu_csr(tmp_path):
+    """a dense diagonal block wider than the LDS window cannot be tiled: tune() says so
+    and binds the general CSR kernel (still on the GPU); the self-check still passes"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n, k = 3000, 300
+    B = sp.random(n, n, density=0.002, random_state=3, format="lil")
+    B[1000:1000 + k, 1000:1000 + k] = rng.uniform(-1, 0, (k, k))
+    A = sp.tril(B.tocsr(), -1)
+    A = (A + A.T + sp.diags(np.full(n, 400.0))).tocsr()
+    A.sort_indices()
+    p = str(tmp_path / "block.mtx")
+    from cfs_spmv_amd import synth
+    synth.write_mtx(p, n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data)
+    env = dict(os.environ, CFS_SEED="7", CFS_HIP_MAX_SLOTS="128")
+    r = subprocess.run([os.path.join(ROOT, "build", "test_spmv_mmf"), p, "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout + r.stderr
+    assert "falling back to the general CSR kernel" in r.stdout, r.stdout
+
+
 def test_binary_cache_roundtrip(tmp_path, monkeypatch):
     """CFS_MTX_CACHE_DIR: second load comes from <dir>/<file>.f64.csrbin, a touched
     source file invalidates it"""
