@@ -62,6 +62,12 @@ def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    try:  # a container may show every host core and still grant only a CPU quota
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
     T = max(1, min(cores, 96))  # MaxThreads = 96, include/utils/runtime.hpp:15
     os.environ.setdefault("OMP_PROC_BIND", "close")
     os.environ.setdefault("OMP_PLACES", "cores")

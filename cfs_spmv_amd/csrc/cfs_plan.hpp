@@ -31,6 +31,9 @@
 //     groups, groups of neighbouring rows on the same XCD (blockIdx % 8).
 #pragma once
 
+#include <omp.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cstdint>
@@ -92,6 +95,33 @@ constexpr int kDefaultSlots = 4992;    // 2 workgroups x (4992 x 16 B + 16 B) fi
 constexpr int kDefaultBlock = 512;    // 8 waves per workgroup, 16 per CU (measured best)
 constexpr int kStaticLds = 16;        // slice ticket counter
 constexpr int kSlotsPerThread = 10;   // LDS slots one thread fills/flushes (registers)
+
+// Threads for the host-side schedule build: the OpenMP default, capped by the
+// affinity mask and by the cgroup CPU quota (a container that shows 256 cores but
+// grants 16 CPUs of time makes 256 spinning threads many times slower than 16;
+// measured on the MI355X boxes).  CFS_HOST_THREADS overrides.
+inline int host_threads() {
+  static int cached = 0;
+  if (cached > 0) return cached;
+  int t = omp_get_max_threads();
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0)
+    t = std::min(t, (int)CPU_COUNT(&set));
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long quota = atol(q);
+      if (quota > 0) t = std::min<long>(t, (quota + period - 1) / period);
+    }
+    fclose(f);
+  }
+  if (const char *e = getenv("CFS_HOST_THREADS"))
+    if (atoi(e) > 0) t = atoi(e);
+  cached = std::max(1, t);
+  return cached;
+}
 
 template <typename V> struct SymPlan {
   // problem
@@ -228,7 +258,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   // ---- lower counts -----------------------------------------------------
   std::vector<int32_t> lcnt(rows, 0);
   int64_t nnz_low = 0, nnz_diag = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nnz_low, nnz_diag)
+#pragma omp parallel for schedule(static) reduction(+ : nnz_low, nnz_diag) num_threads(host_threads())
   for (int i = rb; i < re; i++) {
     int c = 0;
     for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
@@ -293,7 +323,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     // with its own "column already counted for tile id" stamps.
     std::vector<std::vector<Tile>> per_group(ngroups);
     std::string cut_error;
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
     {
       std::vector<int32_t> stamp(n > 0 ? n : 1, -1);
       int tid = 0;
@@ -424,7 +454,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   std::vector<int64_t> tile_len(T, 0);
   {
     std::vector<int32_t> nv(T, 0);
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
     {
       std::vector<VRow> vr;
 #pragma omp for schedule(dynamic, 1)
@@ -482,7 +512,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
         seen++;
       }
   };
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
   {
     std::vector<VRow> vr;
     std::vector<int32_t> prev, cur;
@@ -559,7 +589,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   }
   pt.lap("core: vrows + sizes");
   bool dup_error = false;
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
   {
     std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
     std::vector<int32_t> hcols, lowj;
@@ -893,7 +923,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     return -1;
   };
   std::vector<int32_t> brp((size_t)n + 2, 0);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_threads())
   for (int p = rb; p < re; p++) {
     const int i = perm[p - rb];
     int cnt = 0;
@@ -909,7 +939,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   std::vector<int32_t> bci((size_t)bnnz + 1);
   std::vector<V> bva((size_t)bnnz + 1);
   bool asym = false;
-#pragma omp parallel
+#pragma omp parallel num_threads(host_threads())
   {
     std::vector<std::pair<int32_t, V>> tmp;
 #pragma omp for schedule(dynamic, 256)

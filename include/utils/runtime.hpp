@@ -17,6 +17,9 @@ const int MaxThreads = 96;
 
 // CFS_NUM_THREADS: unset -> 1, negative -> 1, "0" stays 0 (as in the reference)
 size_t get_num_threads();
+// threads for host-side work (parallel reader): the OpenMP default capped by the
+// affinity mask and the cgroup CPU quota; CFS_HOST_THREADS overrides
+int get_host_threads();
 // CFS_DEVICE: HIP device ordinal this process binds to (default 0)
 int get_device();
 // number of HIP devices visible; 0 means the GPU path cannot run

@@ -1,6 +1,7 @@
 // mmf.cpp -- parallel Matrix-Market reader (see include/io/mmf.hpp for the
 // contract and for what it mirrors in the reference).
 #include "io/mmf.hpp"
+#include "utils/runtime.hpp"
 
 #include <fcntl.h>
 #include <omp.h>
@@ -239,7 +240,7 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
 
   // ---- entries: cut the body at line boundaries, parse in parallel --------------
   const char *body = p;
-  const int nth = std::max(1, omp_get_max_threads());
+  const int nth = std::max(1, cfs::util::runtime::get_host_threads());
   std::vector<const char *> cut(nth + 1, end);
   cut[0] = body;
   for (int i = 1; i < nth; i++) {
@@ -341,7 +342,7 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
   out.rowptr.resize((size_t)nrows + 1);
   out.colind.resize((size_t)nnz);
   out.values.resize((size_t)nnz);
-#pragma omp parallel for schedule(dynamic, 1024)
+#pragma omp parallel for schedule(dynamic, 1024) num_threads(nth)
   for (long r = 0; r < nrows; r++) {
     CV *b = buf.data() + rowcnt[r], *e = buf.data() + rowcnt[r + 1];
     // (col, input order): duplicates keep their file order

@@ -1,9 +1,12 @@
 // runtime.cpp -- environment knobs (reference: src/runtime.cpp:10-34).
 #include "utils/runtime.hpp"
 
+#include <omp.h>
 #include <sched.h>
 
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 
 #include "cfs_hip.h"
@@ -20,6 +23,30 @@ size_t get_num_threads() {
     if (ret < 0) ret = 1;
   }
   return ret;
+}
+
+int get_host_threads() {
+  static int cached = 0;
+  if (cached > 0) return cached;
+  long t = omp_get_max_threads();
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0 && CPU_COUNT(&set) > 0 && CPU_COUNT(&set) < t)
+    t = CPU_COUNT(&set);
+  // a container may show every core of the host and still grant only a quota
+  if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[64];
+    long period = 0;
+    if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      const long quota = atol(q);
+      if (quota > 0 && (quota + period - 1) / period < t) t = (quota + period - 1) / period;
+    }
+    fclose(f);
+  }
+  const char *env = getenv("CFS_HOST_THREADS");
+  if (env && atoi(env) > 0) t = atoi(env);
+  cached = t < 1 ? 1 : (int)t;
+  return cached;
 }
 
 int get_device() {
