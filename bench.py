@@ -53,24 +53,28 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
-    """the oracle's restatement of cpu_mv_sym_conflict_free_v2 on the host cores,
-    same matrix, same x, reference protocol (loops/2 warm-up, loops timed)"""
-    from oracle import oracle
+def host_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup quota (a
+    container may show every core of the host and still grant only a share)"""
     cores = os.cpu_count() or 1
     try:
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    try:  # a container may show every host core and still grant only a CPU quota
+    try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
         if quota != "max":
             cores = min(cores, max(1, -(-int(quota) // int(period))))
     except Exception:
         pass
-    T = max(1, min(cores, 96))  # MaxThreads = 96, include/utils/runtime.hpp:15
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
+    return max(1, cores)
+
+
+def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
+    """the oracle's restatement of cpu_mv_sym_conflict_free_v2 on the host cores,
+    same matrix, same x, reference protocol (loops/2 warm-up, loops timed)"""
+    from oracle import oracle
+    T = max(1, min(host_cpus(), 96))  # MaxThreads = 96, include/utils/runtime.hpp:15
     t0 = time.time()
     o = oracle.SymOracle(n, rp, ci, va, T)
     preproc = time.time() - t0
@@ -95,6 +99,13 @@ def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
 
 def main():
     args = parse()
+    # host-side setup (matrix generator, schedule build) is OpenMP code: give every
+    # rank of this node an equal share of the CPUs (torchrun presets
+    # OMP_NUM_THREADS=1 for N > 1, which would serialise it).  Set before any
+    # OpenMP runtime is loaded.
+    share = max(1, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    os.environ["OMP_NUM_THREADS"] = str(share)
+    os.environ["CFS_HOST_THREADS"] = str(share)
     import numpy as np
     import torch
     import cfs_spmv_amd as cfs

@@ -7,6 +7,7 @@ directory is `cfs_spmv_amd`.)
   _lib.py                              ctypes binding of include/cfs_hip.h
   matrix.py                            SparseMatrix / SpDMV mirror over the C ABI
   dist.py                              1-D row-block sharding over torch.distributed
+  solver.py                            solver-style caller (CG): every product fed back as the next x
   synth.py, csrc/cfs_synth.c           synthetic SuiteSparse stand-ins (workload only)
 """
 from ._lib import CfsHipError, load, lib_path  # noqa: F401

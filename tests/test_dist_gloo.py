@@ -124,3 +124,56 @@ def test_sharded_exchange_gloo(world, name, scale, exchange):
         assert err <= 1e-12 and ok_rows, (rank, err)
     assert sum(r[3] for r in res) == sum(r[4] for r in res) > 0  # every packed value arrives
     assert res[0][3] == 0  # rank 0 owns the first rows: nothing to send
+
+
+def _cg_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch
+        import torch.distributed as dist
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        import cfs_spmv_amd as cfs
+        from cfs_spmv_amd import synth
+        from cfs_spmv_amd.dist import ShardedSym
+        from cfs_spmv_amd.solver import cg_sharded
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n, rp, ci, va, _ = synth.generate("pwtk", 0.02)
+        rs = cfs.balanced_splits(n, rp, ci, world)
+        be = HostShardDouble(n, rp, ci, va, world, rank, rs)
+        sh = ShardedSym(be, world, rank, np.float64, torch.device("cpu"))
+        b = synth.make_x(n, 7)
+        bb = torch.from_numpy(b[be.row_begin:be.row_end].copy())
+        u, it, res = cg_sharded(sh, rs, bb, tol=1e-11, maxiter=400)
+        u_ref = spl.spsolve(sp.csc_matrix(sp.csr_matrix((va, ci, rp), shape=(n, n))), b)
+        err = float(np.max(np.abs(u.numpy() - u_ref[be.row_begin:be.row_end])) / np.max(np.abs(u_ref)))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, err, it, res))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, f"{e}\n{traceback.format_exc()}", 0, 0.0))
+
+
+def test_sharded_cg_gloo():
+    """solver-style loop over the sharded path: every product is fed back as the next
+    input through the y -> x all-gather"""
+    import torch.multiprocessing as mp
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, it, rr in res:
+        assert not isinstance(err, str), f"rank {rank} failed: {err}"
+        assert err <= 1e-9 and rr <= 1e-10 and 0 < it < 400, (rank, err, it, rr)
+    assert res[0][2] == res[1][2]  # same iteration count on every rank
