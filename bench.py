@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-loops", type=int, default=32)
-    ap.add_argument("--exchange", default="all_to_all", choices=["all_to_all", "reduce_scatter"],
-                    help="N>1: sparse all-to-all of the touched rows (default) or the dense "
-                         "reduce-scatter of padded blocks")
+    ap.add_argument("--exchange", default="none", choices=["none", "all_to_all", "reduce_scatter"],
+                    help="N>1: 'none' = mirrored shards, every off-block entry is stored by both "
+                         "ranks it touches and no SpMV needs a collective (default); "
+                         "'all_to_all' = packed contributions to lower ranks, one sparse "
+                         "all-to-all; 'reduce_scatter' = the dense form over padded blocks")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the tile kernel with HIP events on every n-th timed step")
     return ap.parse_args()
@@ -158,11 +160,11 @@ def main():
         A = cfs.SymMatrix(n, rp, ci, va, options=opt)
         sh = None
     else:
-        from cfs_spmv_amd.dist import ShardedSym
+        from cfs_spmv_amd.dist import build_shard
         rs = cfs.balanced_splits(n, rp, ci, N)
-        A = cfs.SymMatrix(n, rp, ci, va, options=opt, row_splits=rs, rank=rank)
-        sh = ShardedSym(A, N, rank, np_dt, dev, stage_via_host=(backend != "nccl"),
-                        exchange=args.exchange, row_splits=rs)
+        A, sh, args.exchange = build_shard(n, rp, ci, va, N, rank, rs, dev, options=opt,
+                                           exchange=args.exchange,
+                                           stage_via_host=(backend != "nccl"))
     preproc = time.time() - t0
     st = A.stats()
     rows = st["row_end"] - st["row_begin"]
@@ -170,6 +172,8 @@ def main():
     y = torch.full((rows,), float("nan"), dtype=t_dt, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     send = sh.send_buf if sh is not None else None
+    # one GPU, or mirrored shards: an SpMV is the local launch sequence, no collective
+    local_only = sh is None or args.exchange == "none"
 
     import ctypes as C
 
@@ -194,15 +198,15 @@ def main():
             _lib.check(lib.cfs_hip_event_record(ev0[i], stream))
             A.spmv_phases(y, x, send, 1)
             _lib.check(lib.cfs_hip_event_record(ev1[i], stream))
-            if sh is None:
+            if local_only:
                 A.spmv_phases(y, x, send, 2)
             else:
                 A.spmv_phases(y, x, send, 4)
-        elif sh is None:
+        elif local_only:
             A.spmv_phases(y, x, send, 3)
         else:
             A.spmv_phases(y, x, send, 1 | 4)
-        if sh is not None:
+        if not local_only:
             sh.finish(y, x)   # exchange || local fold, then fold of what arrived
 
     def barrier():
@@ -278,7 +282,10 @@ def main():
                             f"scale {args.scale}: n={n}, nnz_full={nnz_full}, "
                             f"nnz_low={nnz_low}, symmetric SSS SpMV y=Ax",
                 "format": "sss", "sharding": f"1d-row-blocks x{N}",
-                "exchange": args.exchange if N > 1 else None,
+                "exchange": (None if sh is None else
+                             "none: off-block entries mirrored on both ranks, no collective "
+                             "per SpMV" if args.exchange == "none" else args.exchange),
+                "mirror_entries_rank0": st.get("mirror_entries", 0),
                 "algorithmic_bytes_per_spmv": int(nnz_low * (4 + va.itemsize)
                                                   + n * (4 + 3 * va.itemsize)),
                 "effective_GBps_whole_step": round(

@@ -24,7 +24,7 @@ class SymStats(C.Structure):
                 ("halo_slots", C.c_int64), ("fold_rows", C.c_int64),
                 ("remote_vals", C.c_int64), ("lds_bytes", C.c_int64),
                 ("bytes_algorithmic", C.c_int64), ("bytes_streamed", C.c_int64),
-                ("device_bytes", C.c_int64)]
+                ("device_bytes", C.c_int64), ("mirror_entries", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -34,7 +34,8 @@ class PlanReport(C.Structure):
     _fields_ = [("ntiles", C.c_int), ("ngroups", C.c_int), ("lds_slots", C.c_int),
                 ("nslices", C.c_int64), ("halo_slots", C.c_int64), ("stream_len", C.c_int64),
                 ("nnz_low", C.c_int64), ("fold_rows", C.c_int64), ("remote_vals", C.c_int64),
-                ("decoded", C.c_int64), ("mismatches", C.c_int64)]
+                ("decoded", C.c_int64), ("mismatches", C.c_int64),
+                ("mirror_entries", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

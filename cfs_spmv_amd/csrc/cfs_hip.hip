@@ -133,28 +133,34 @@ __device__ __forceinline__ uint32_t slot_block(unsigned long long leaders, int c
 // (measured: fp32 tile kernel 0.370 ms with ds_add_f32 vs 0.084 ms without the
 // transposed atomics), so the single-precision build accumulates the window in
 // double and rounds once when the window is flushed.
-template <typename V, int MODE>
-__device__ __forceinline__ void lds_update(const V *xl, double *yl, V a, unsigned c, V xi, V &acc) {
+// OFFB (a mirrored shard, cfs_plan::Options::mirror_offblock): slots >= ny are
+// off-block columns; their entries are one-sided -- row side only, the rank that
+// owns the column computes the transposed side from its own copy of the entry.
+template <typename V, int MODE, bool OFFB>
+__device__ __forceinline__ void lds_update(const V *xl, double *yl, V a, unsigned c, V xi, V &acc,
+                                           unsigned ny) {
   if (MODE == 2) {
     acc = fma(a, xi + V(c), acc);
   } else {
     acc = fma(a, xl[c], acc);
-    if (MODE == 0) atomicAdd(&yl[c], (double)a * (double)xi);
+    if (MODE == 0 && (!OFFB || c < ny)) atomicAdd(&yl[c], (double)a * (double)xi);
   }
 }
-template <typename V, int MODE>
-__device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, double *yl, V xi, V &acc) {
-  lds_update<V, MODE>(xl, yl, p.v[0], p.c.x, xi, acc);
-  lds_update<V, MODE>(xl, yl, p.v[1], p.c.y, xi, acc);
-  lds_update<V, MODE>(xl, yl, p.v[2], p.c.z, xi, acc);
-  lds_update<V, MODE>(xl, yl, p.v[3], p.c.w, xi, acc);
+template <typename V, int MODE, bool OFFB>
+__device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, double *yl, V xi,
+                                               V &acc, unsigned ny) {
+  lds_update<V, MODE, OFFB>(xl, yl, p.v[0], p.c.x, xi, acc, ny);
+  lds_update<V, MODE, OFFB>(xl, yl, p.v[1], p.c.y, xi, acc, ny);
+  lds_update<V, MODE, OFFB>(xl, yl, p.v[2], p.c.z, xi, acc, ny);
+  lds_update<V, MODE, OFFB>(xl, yl, p.v[3], p.c.w, xi, acc, ny);
 }
 // one COO leftover a = A[row(r)][col(c)]: both sides through LDS atomics
-template <typename V, int MODE>
-__device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigned r, unsigned c) {
+template <typename V, int MODE, bool OFFB>
+__device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigned r, unsigned c,
+                                           unsigned ny) {
   if (MODE == 0 || MODE == 1) {
     atomicAdd(&yl[r], (double)a * (double)xl[c]);
-    if (MODE == 0) atomicAdd(&yl[c], (double)a * (double)xl[r]);
+    if (MODE == 0 && (!OFFB || c < ny)) atomicAdd(&yl[c], (double)a * (double)xl[r]);
   }
 }
 
@@ -176,7 +182,7 @@ __device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigne
 // as a result path): 1 = no transposed LDS atomics, 2 = no LDS traffic at all,
 // 3 = windows only (no matrix stream), 4 = matrix stream only (no windows).
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int MODE, bool NT>
+template <typename V, int BLOCK, int MODE, bool NT, bool OFFB>
 __global__ void __launch_bounds__(BLOCK)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const Tile *__restrict__ a_gfirst,
                         const int32_t *__restrict__ a_group_ptr,
@@ -275,6 +281,7 @@ __global__ void __launch_bounds__(BLOCK)
   for (int ti = t0; ti < t1; ++ti) {
     const Tile t = ti == t0 ? tfirst : d.tiles[ti];
     const int nown = t.nown, nslots = t.nslots;
+    const unsigned ny = OFFB ? (unsigned)t.ny : (unsigned)nslots; // slots with a y window
     const int vrow0 = t.vrow_off, nvr = t.nvrows;
     const V *tv = d.vals + t.nnz_off;
     const uint16_t *ts = d.slots + t.sl_off;
@@ -373,11 +380,11 @@ __global__ void __launch_bounds__(BLOCK)
         const int cnt1 = __popcll(__ballot(a > g + 1));
         const uint32_t off1 = off + 4u * (uint32_t)cnt, soff1 = soff + slot_block(leaders, cnt);
         fetch_packet<NT>(B, tv, ts, off1, soff1, cnt1, leaders, lane);
-        if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
+        if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
         const int cnt2 = __popcll(__ballot(a > g + 2));
         const uint32_t off2 = off1 + 4u * (uint32_t)cnt1, soff2 = soff1 + slot_block(leaders, cnt1);
         fetch_packet<NT>(A, tv, ts, off2, soff2, cnt2, leaders, lane);
-        if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
+        if (a > g + 1) consume_packet<V, MODE, OFFB>(B, xl, yl, xi, acc, ny);
         g += 2;
         off = off2;
         soff = soff2;
@@ -387,10 +394,10 @@ __global__ void __launch_bounds__(BLOCK)
         const int cnt1 = __popcll(__ballot(a > g + 1));
         fetch_packet<NT>(B, tv, ts, off + 4u * (uint32_t)cnt, soff + slot_block(leaders, cnt), cnt1,
                      leaders, lane);
-        if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
-        if (a > g + 1) consume_packet<V, MODE>(B, xl, yl, xi, acc);
+        if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
+        if (a > g + 1) consume_packet<V, MODE, OFFB>(B, xl, yl, xi, acc, ny);
       } else if (amax - g == 1) {
-        if (a > g) consume_packet<V, MODE>(A, xl, yl, xi, acc);
+        if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
       }
       if (s_cur * 64 + lane < nvr) atomicAdd(&yl[r], (double)fma(dg, xi, acc));
     }
@@ -406,10 +413,10 @@ __global__ void __launch_bounds__(BLOCK)
         Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
       }
       const int e0 = cp * 256 + lane * 4;
-      if (e0 + 0 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[0], Qr.x, Q.c.x);
-      if (e0 + 1 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[1], Qr.y, Q.c.y);
-      if (e0 + 2 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[2], Qr.z, Q.c.z);
-      if (e0 + 3 < t.ncoo) coo_update<V, MODE>(xl, yl, Q.v[3], Qr.w, Q.c.w);
+      if (e0 + 0 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[0], Qr.x, Q.c.x, ny);
+      if (e0 + 1 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[1], Qr.y, Q.c.y, ny);
+      if (e0 + 2 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[2], Qr.z, Q.c.z, ny);
+      if (e0 + 3 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[3], Qr.w, Q.c.w, ny);
     }
     if (dbg && lane == 0 && wave == 0 && ti + 1 == t1) dbg[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     if (ti + 1 < t1) gather_x(d.tiles[ti + 1]); // lands behind the barrier + flush
@@ -428,7 +435,7 @@ __global__ void __launch_bounds__(BLOCK)
       for (int k = 0; k < U; ++k) {
         const int i = tid + k * BLOCK;
         if (i < nown) y[yidx[k]] = (V)yl[i];
-        else if (i < nslots) d.strip[t.halo_off + (i - nown)] = (V)yl[i];
+        else if (i < (int)ny) d.strip[t.halo_off + (i - nown)] = (V)yl[i];
       }
     }
   }
@@ -643,6 +650,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int nfold = 0, nsend = 0, nrfold = 0;
   int ablate_mode = 0; // cfs_hip_options.flags & 7 (timing-only ablations)
   bool nt_stream = true; // matrix stream larger than the Infinity Cache: non-temporal loads
+  bool offblock = false; // some tile has one-sided (off-block) slots: mirrored shard
+  int64_t mirror_entries = 0;
   unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
   size_t lds_bytes = 0;
   int64_t halo_slots = 0, stream_len = 0, slot_len = 0, nslices = 0, coo_len = 0;
@@ -675,6 +684,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
 #undef UP
     if ((rc = strip.alloc((size_t)P.nhalo * sizeof(V)))) return rc;
     halo_slots = P.nhalo;
+    offblock = P.onesided_slots > 0;
+    mirror_entries = P.mirror_entries;
     stream_len = P.stream_len;
     slot_len = P.slot_len;
     nslices = (int64_t)P.slice_meta.size();
@@ -713,8 +724,11 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   }
 
   template <int BLOCK, int MODE, bool NT> int raise_attr() {
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, MODE, NT>,
+    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, MODE, NT, false>,
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    if (MODE == 0)
+      HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 0, NT, true>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     return 0;
   }
   template <int BLOCK> int raise_one() {
@@ -733,8 +747,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     }
   }
 
-  template <int BLOCK, int MODE, bool NT> void launch_one(V *y, const V *x, hipStream_t st) {
-    hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, MODE, NT>), dim3(P.ngroups), dim3(BLOCK),
+  template <int BLOCK, int MODE, bool NT, bool OFFB = false>
+  void launch_one(V *y, const V *x, hipStream_t st) {
+    hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, MODE, NT, OFFB>), dim3(P.ngroups), dim3(BLOCK),
                        lds_bytes, st, dev.tiles, dev.gfirst, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
                        dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
                        dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
@@ -746,8 +761,13 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     case 3: launch_one<BLOCK, 3, true>(y, x, st); break;
     case 4: launch_one<BLOCK, 4, true>(y, x, st); break;
     default:
-      if (nt_stream) launch_one<BLOCK, 0, true>(y, x, st);
-      else launch_one<BLOCK, 0, false>(y, x, st);
+      if (offblock) { // mirrored shard: one-sided off-block slots
+        if (nt_stream) launch_one<BLOCK, 0, true, true>(y, x, st);
+        else launch_one<BLOCK, 0, false, true>(y, x, st);
+      } else {
+        if (nt_stream) launch_one<BLOCK, 0, true>(y, x, st);
+        else launch_one<BLOCK, 0, false>(y, x, st);
+      }
     }
   }
 
@@ -820,6 +840,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     o->fold_rows = nfold;
     o->remote_vals = nsend;
     o->lds_bytes = (int64_t)lds_bytes;
+    o->mirror_entries = mirror_entries;
     o->bytes_algorithmic = P.nnz_low * (4 + s) + rows_ * (4 + 3 * s);
     o->bytes_streamed = stream_len * s + slot_len * 2 + coo_len * (s + 4) + rows_ * (4 + 3 * s) +
                         halo_slots * (4 + 2 * s) + rows_ * 8 /* slot_col, x, strip st */
@@ -950,6 +971,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     r.flags = o->flags;
     r.reorder = !(o->flags & CFS_HIP_FLAG_NO_REORDER);
     if (o->flags & CFS_HIP_FLAG_FORCE_CLUSTER) r.force_order = 2;
+    if (o->flags & CFS_HIP_FLAG_SHARD_EXCHANGE) r.mirror_offblock = false;
   }
   // tuning knob for callers that cannot pass options (the C++ surface): LDS slots
   // per tile, like CFS_NUM_THREADS for the reference's partitions
@@ -965,7 +987,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
 // resident wave of workgroups (a workgroup that has to wait for a slot would
 // run as a second round and double the launch time)
 template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
-  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true>;
+  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true, true>;
   HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k, BLOCK, lds));
   return 0;
@@ -1257,9 +1279,38 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
     A.reserve(r.size());
     B.reserve(r.size());
     for (size_t k = 0; k < r.size(); k++) A.push_back(Tr{r[k], c[k], bits(v[k])});
+    auto lower_pos = [&](int hi, int lo) {
+      for (int q = rowptr[hi]; q < rowptr[hi + 1]; q++)
+        if (colind[q] == lo) return q;
+      return -1;
+    };
+    int64_t mirrored = 0;
     for (int i = P.row_begin; i < P.row_end; i++)
-      for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
         if (colind[j] < i) B.push_back(Tr{i, colind[j], bits(values[j])});
+        else if (P.mirrored && colind[j] >= P.row_end) {
+          // mirrored shard: the entry (c, i) of a higher rank's row c, with the
+          // value of the LOWER triangle
+          const int q = lower_pos(colind[j], i);
+          if (q < 0) bad++;
+          else B.push_back(Tr{colind[j], i, bits(values[q])});
+          mirrored++;
+        }
+      }
+    if (mirrored != P.mirror_entries) bad++;
+    rep->mirror_entries = P.mirror_entries;
+    // y window classes: slots [nown, ny) are in-block columns, [ny, nslots) are not
+    for (const Tile &t : P.tiles) {
+      if (t.ny < t.nown || t.ny > t.nslots) bad++;
+      for (int h = 0; h < t.nslots - t.nown; h++) {
+        const int c = P.halo_col[t.halo_off + h];
+        const bool inblock = c >= P.row_begin && c < P.row_end;
+        // mirrored shard: exactly the in-block columns have a y window entry;
+        // exchange form / whole matrix: every slot has one, no column right of the block
+        if (P.mirrored ? inblock != (t.nown + h < t.ny) : (t.ny != t.nslots || c >= P.row_end)) bad++;
+      }
+    }
+    if (P.mirrored && !P.send_row.empty()) bad++;
     std::sort(A.begin(), A.end());
     std::sort(B.begin(), B.end());
     if (A.size() != B.size()) bad += 1 + (int64_t)(A.size() > B.size() ? A.size() - B.size() : B.size() - A.size());
@@ -1289,8 +1340,10 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
         int s = P.send_idx[q];
         if (seen[s]++ || P.halo_col[s] != P.send_row[i]) bad++;
       }
+    int64_t uncovered = 0;
     for (char s : seen)
-      if (!s) bad++;
+      if (!s) uncovered++;
+    if (uncovered != P.onesided_slots) bad++; // one-sided slots have nothing to fold or send
   }
   // (3) groups partition the tiles; tiles partition the rows
   {

@@ -58,6 +58,13 @@ struct Options {
   // (Per-GROUP shares from per-workgroup finish times do not help: workgroups of
   // one CU finish in dispatch order whatever their shares, the CU total counts.)
   std::vector<double> group_share;
+  // Shards (nranks > 1): off-block entries are stored by BOTH ranks they touch and
+  // processed one-sided (row side only): a row of the block also carries its
+  // entries a_ri of rows r owned by higher ranks, and its entries left of the
+  // block no longer update y of the lower rank.  No contribution ever leaves
+  // the rank, so an SpMV needs no exchange at all (x is replicated anyway).
+  // false = the exchange form: contributions to lower ranks are packed and sent.
+  bool mirror_offblock = true;
   int wg_per_cu = 0; // measured residency of the tile kernel (0 = estimate)
   int num_cus = 0;   // compute units of the device (0 = 256, MI355X)
 };
@@ -77,7 +84,8 @@ struct Tile {
   int32_t slot_off;   // offset of this tile's slots in slot_col[]
   int32_t vrow_off;   // offset of this tile's virtual rows in rowinfo[] / diag[]
   int32_t nvrows;     // virtual rows (>= nown: long rows are split over lanes)
-  int32_t pad_;
+  int32_t ny;         // slots with a y window entry: own rows + in-block halo; slots
+                      // [ny, nslots) are off-block columns of a mirrored shard (x only)
 };
 static_assert(sizeof(Tile) == 64, "Tile must stay 64 bytes");
 
@@ -158,6 +166,9 @@ template <typename V> struct SymPlan {
   std::vector<int32_t> rfold_row, rfold_ptr, rfold_idx;
   int64_t stream_len = 0;
   int64_t nhalo = 0; // halo slots (halo_col carries one extra padding entry)
+  bool mirrored = false;    // shard built with mirror_offblock (no sends)
+  int64_t mirror_entries = 0; // one-sided entries stored for rows of higher ranks
+  int64_t onesided_slots = 0; // halo slots without a y window
   std::string error;
 };
 
@@ -254,20 +265,58 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   P.max_slots = max_slots;
   const int64_t max_tile_nnz =
       opt.max_tile_nnz > 0 ? opt.max_tile_nnz : (int64_t)1 << 30;
+  // which entries of row i does the schedule store?  The strict lower triangle,
+  // and -- for a mirrored shard -- the entries right of the block (rows of higher
+  // ranks that hold a_ci: their transposed update of y_i is computed HERE)
+  const bool mirror = opt.mirror_offblock && nranks > 1;
+  P.mirrored = mirror;
+  auto stored = [&](int i, int c) { return c < i || (mirror && c >= re); };
+  // natural order: `values` is the caller's full CSR and the value of a mirrored
+  // entry (i, c), c >= re, is the LOWER entry (c, i) -- all the reference's SSS
+  // path reads.  Clustered order (perm_in): the caller resolved it already.
+  bool mirror_fail = false;
+  auto val_at = [&](int i, int j) -> V {
+    const int c = colind[j];
+    if (!mirror || c < re || perm_in) return values[j];
+    int b = rowptr[c], e = rowptr[c + 1], l = b, r = e;
+    while (l < r) {
+      int m = (l + r) >> 1;
+      if (colind[m] < i) l = m + 1;
+      else r = m;
+    }
+    if (l < e && colind[l] == i) return values[l];
+    for (int q = b; q < e; q++)
+      if (colind[q] == i) return values[q];
+    mirror_fail = true; // structurally unsymmetric input
+    return V(0);
+  };
 
   // ---- lower counts -----------------------------------------------------
   std::vector<int32_t> lcnt(rows, 0);
-  int64_t nnz_low = 0, nnz_diag = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nnz_low, nnz_diag) num_threads(host_threads())
+  int64_t nnz_low = 0, nnz_diag = 0, nnz_mirror = 0, mirror_dup = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nnz_low, nnz_diag, nnz_mirror, mirror_dup) num_threads(host_threads())
   for (int i = rb; i < re; i++) {
-    int c = 0;
+    int c = 0, up = 0, prev_up = -1;
+    bool dup = false;
     for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
       if (colind[j] < i) c++;
       else if (colind[j] == i) nnz_diag++;
+      else if (mirror && colind[j] >= re) {
+        if (colind[j] <= prev_up) dup = true; // duplicate / unsorted: cannot pair with (c, i)
+        prev_up = colind[j];
+        up++;
+      }
     }
-    lcnt[i - rb] = c;
+    lcnt[i - rb] = c + up;
     nnz_low += c;
+    nnz_mirror += up;
+    if (dup) mirror_dup++;
   }
+  if (mirror_dup) {
+    P.error = "mirror: duplicate or unsorted off-block entries";
+    return false;
+  }
+  P.mirror_entries = nnz_mirror;
   P.nnz_low = nnz_low;
   P.nnz_diag = nnz_diag;
   P.nnz_full = 2 * nnz_low + nnz_diag;
@@ -339,9 +388,9 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
             int newh = 0, len = 0;
             for (int j = rowptr[row]; j < rowptr[row + 1]; j++) {
               int c = colind[j];
-              if (c >= row) continue;
+              if (!stored(row, c)) continue;
               len++;
-              if (c < t.row0 && stamp[c] != tid) {
+              if ((c < t.row0 || c >= re) && stamp[c] != tid) {
                 stamp[c] = tid;
                 newh++;
               }
@@ -507,7 +556,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     out.clear();
     int seen = 0;
     for (int j = rowptr[i]; j < rowptr[i + 1] && (int)out.size() < cnt; j++)
-      if (colind[j] < i) {
+      if (stored(i, colind[j])) {
         if (seen >= k0) out.push_back(colind[j]);
         seen++;
       }
@@ -597,26 +646,38 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 #pragma omp for schedule(dynamic, 1)
     for (int ti = 0; ti < T; ti++) {
       const Tile &t = P.tiles[ti];
-      // halo: unique columns < row0, ascending
+      // halo: unique stored columns outside the tile; in-block columns (they get
+      // a y window entry and a strip entry) first, then the off-block columns of
+      // a mirrored shard (x only), each class ascending
       hcols.clear();
       for (int r = 0; r < t.nown; r++) {
         int i = t.row0 + r;
         for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
           int c = colind[j];
-          if (c < t.row0 && colmap[c] < 0) {
+          if (stored(i, c) && (c < t.row0 || c >= re) && colmap[c] < 0) {
             colmap[c] = 0;
             hcols.push_back(c);
           }
         }
       }
-      std::sort(hcols.begin(), hcols.end());
+      auto offblock = [&](int c) { return mirror && (c < rb || c >= re); };
+      std::sort(hcols.begin(), hcols.end(), [&](int a, int b) {
+        const bool oa = offblock(a), ob = offblock(b);
+        return oa != ob ? ob : a < b;
+      });
       if ((int)hcols.size() != t.nslots - t.nown) dup_error = true;
+      {
+        int ny = t.nown;
+        for (int c : hcols)
+          if (!offblock(c)) ny++;
+        P.tiles[ti].ny = ny;
+      }
       for (size_t h = 0; h < hcols.size(); h++) {
         colmap[hcols[h]] = t.nown + (int)h;
         P.halo_col[t.halo_off + h] = hcols[h];
       }
       auto slot_of = [&](int c) {
-        return (uint16_t)(c >= t.row0 ? c - t.row0 : colmap[c]);
+        return (uint16_t)((c >= t.row0 && c < re) ? c - t.row0 : colmap[c]);
       };
       // positions (in the CSR) of the lower entries of local row r, in stored
       // order -- works whether or not the columns of a row ascend
@@ -624,7 +685,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
         out.clear();
         int i = t.row0 + r;
         for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
-          if (colind[j] < i) out.push_back(j);
+          if (stored(i, colind[j])) out.push_back(j);
       };
       build_vrows(t, vr);
       V *tv = P.vals.data() + t.nnz_off;
@@ -656,7 +717,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
             if (is_leader) lead++;
             for (int j = 0; j < kPacket; j++) {
               int q = low[l][(vr[p0 + l].k0 + g) * kPacket + j];
-              tv[o + packet_val_pos<V>(l, j, cnt)] = values[q];
+              tv[o + packet_val_pos<V>(l, j, cnt)] = val_at(t.row0 + vr[p0 + l].r, q);
               if (is_leader) ts[os + packet_slot_pos(lead, j)] = slot_of(colind[q]);
             }
           }
@@ -677,7 +738,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
             int q = lowj[k];
             int64_t pk = e >> 8;
             int l = (int)((e & 255) >> 2), j = (int)(e & 3);
-            cv[pk * 256 + packet_val_pos<V>(l, j)] = values[q];
+            cv[pk * 256 + packet_val_pos<V>(l, j)] = val_at(t.row0 + r, q);
             cr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)r;
             cc[pk * 256 + packet_slot_pos(l, j)] = slot_of(colind[q]);
             e++;
@@ -692,6 +753,10 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     P.error = "internal: halo / leftover count mismatch";
     return false;
   }
+  if (mirror_fail) {
+    P.error = "mirror: structurally unsymmetric off-block entries";
+    return false;
+  }
 
   pt.lap("core: fill streams");
   if (getenv("CFS_PLAN_VERBOSE"))
@@ -703,7 +768,8 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     std::vector<int32_t> lcount(rows + 1, 0), rcount(rb + 1, 0);
     for (int64_t q = 0; q < H; q++) {
       int c = P.halo_col[q];
-      if (c >= rb) lcount[c - rb + 1]++;
+      if (c >= rb && c < re) lcount[c - rb + 1]++;
+      else if (mirror) P.onesided_slots++; // x only: nothing to fold, nothing to send
       else rcount[c + 1]++;
     }
     // compact destination lists
@@ -728,8 +794,8 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     std::vector<int32_t> rfill(P.send_ptr.begin(), P.send_ptr.end() - 1);
     for (int64_t q = 0; q < H; q++) { // ascending strip index => tile order
       int c = P.halo_col[q];
-      if (c >= rb) P.fold_idx[lfill[lpos[c - rb]]++] = (int32_t)q;
-      else P.send_idx[rfill[rpos[c]]++] = (int32_t)q;
+      if (c >= rb && c < re) P.fold_idx[lfill[lpos[c - rb]]++] = (int32_t)q;
+      else if (!mirror) P.send_idx[rfill[rpos[c]]++] = (int32_t)q;
     }
     P.send_counts.assign(nranks, 0);
     for (int r : P.send_row) {
@@ -767,7 +833,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   // ---- schedule space -> original indices -------------------------------------
   // the kernels address x and y in the caller's (original) numbering
   {
-    auto orig = [&](int c) { return (perm_in && c >= rb) ? (*perm_in)[c - rb] : c; };
+    auto orig = [&](int c) { return (perm_in && c >= rb && c < re) ? (*perm_in)[c - rb] : c; };
     for (const Tile &t : P.tiles) {
       for (int i = 0; i < t.nown; i++) P.slot_col[t.slot_off + i] = orig(t.row0 + i);
       for (int h = 0; h < t.nslots - t.nown; h++)
@@ -795,14 +861,14 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 template <typename V>
 void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, int ngroups,
                   const std::vector<double> &share, std::vector<int32_t> &perm,
-                  std::vector<int32_t> &chunk) {
+                  std::vector<int32_t> &chunk, bool mirror = false) {
   const int rows = re - rb;
   const int64_t per_nz = (int64_t)sizeof(V) + 2, per_row = 4 + 5 * (int64_t)sizeof(V);
   int64_t total = (int64_t)rows * per_row, inblock = 0;
   for (int i = rb; i < re; i++)
     for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
       int c = colind[j];
-      if (c < rb) total += per_nz;
+      if (c < rb || (mirror && c >= re)) total += per_nz;
       else if (c < re && c != i) inblock++;
     }
   total += inblock / 2 * per_nz;
@@ -848,7 +914,7 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
       const int i = rb + v;
       for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
         const int c = colind[j];
-        if (c < rb) low++;
+        if (c < rb || (mirror && c >= re)) low++;
         else if (c < re && c != i) {
           const int u = c - rb;
           if (state[u] >= 0) low++;
@@ -900,7 +966,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
 
   PhaseTimer pt;
   std::vector<int32_t> perm, chunk;
-  cluster_rows<V>(n, rowptr, colind, rb, re, ngroups, opt.group_share, perm, chunk);
+  const bool mirror = opt.mirror_offblock && nranks > 1;
+  cluster_rows<V>(n, rowptr, colind, rb, re, ngroups, opt.group_share, perm, chunk, mirror);
   pt.lap("cluster_rows");
   std::vector<int32_t> inv(rows);
   for (int p = 0; p < rows; p++) inv[perm[p] - rb] = rb + p;
@@ -929,7 +996,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     int cnt = 0;
     for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
       const int c = colind[j];
-      if (c == i || c < rb) cnt++;
+      if (c == i || c < rb || (mirror && c >= re)) cnt++;
       else if (c < re && inv[c - rb] < p) cnt++;
     }
     brp[p + 1] = cnt;
@@ -950,7 +1017,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
         const int c = colind[j];
         int col;
         if (c == i) col = p;
-        else if (c < rb) col = c;
+        else if (c < rb || (mirror && c >= re)) col = c; // off-block: original numbering
         else if (c < re && inv[c - rb] < p) col = inv[c - rb];
         else continue;
         int src = j; // (i, c) with c <= i is a lower entry itself
@@ -1097,7 +1164,7 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
           {slot_col(cc[pk * 256 + packet_slot_pos(l, j)]),
            cv[pk * 256 + packet_val_pos<V>(l, j)]});
     }
-    auto orig = [&](int c) { return (!P.perm.empty() && c >= rb) ? P.perm[c - rb] : c; };
+    auto orig = [&](int c) { return (!P.perm.empty() && c >= rb && c < P.row_end) ? P.perm[c - rb] : c; };
     for (int rr = 0; rr < t.nown; rr++)
       for (auto &e : rows_out[rr]) {
         const int a = orig(t.row0 + rr), b = orig(e.first);

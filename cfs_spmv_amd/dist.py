@@ -7,11 +7,21 @@ replica of x.  Row-side sums are local.  Transposed updates y_j += a_ij x_i with
 j < R_g are the reference's *direct conflicts* (csr_matrix.tpp:1443-1451); they
 are packed (one value per touched remote row) and exchanged in ONE collective.
 
-The north-star names a reduce-scatter of the off-block contributions.  A dense
-reduce-scatter would move n*s bytes per rank around a ring (~72 us for
-Flan_1565 over xGMI); the contributions only reach the previous
-block(s), so the exchange here is the sparse form of the same reduction: an
-all-to-all of exactly the touched rows, summed on the owner in a fixed order.
+Three forms, selected by `exchange`:
+
+"none" (default)  -- MIRRORED shards: an off-block entry a_ij (i on rank g, j on a
+    lower rank) is stored by both ranks and processed one-sided by each, so no
+    contribution to y ever leaves a rank and an SpMV is one local launch sequence
+    with NO collective (x is replicated anyway; the duplicated boundary entries
+    are a few per cent of a shard).  A sharded SpMV of a ~0.1 ms matrix is bound
+    by latency, and the cheapest exchange is the one that does not happen.
+"all_to_all"      -- the exchange form: contributions to rows of lower ranks are
+    packed (one value per touched remote row) and exchanged in ONE collective,
+    summed on the owner in a fixed order: the sparse form of the reduce-scatter
+    the north-star names (the contributions only reach the previous block(s)).
+"reduce_scatter"  -- the dense form of the same: ONE reduce_scatter_tensor(sum)
+    over nranks equal padded blocks; moves n*s bytes per rank around the ring
+    (~72 us for Flan_1565 over xGMI).
 """
 import numpy as np
 
@@ -23,6 +33,8 @@ class ShardedSym:
 
     def __init__(self, backend, nranks, rank, dtype, device, pg=None, stage_via_host=False,
                  exchange="all_to_all", row_splits=None):
+        # (the class default stays the exchange form: a backend double in the CPU
+        # tests has no mirrored entries; build_shard() below defaults to "none")
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -36,6 +48,16 @@ class ShardedSym:
         send_counts = np.asarray(backend.send_counts(), dtype=np.int64)
         send_rows = np.asarray(backend.send_rows(), dtype=np.int32)
         assert send_counts.sum() == send_rows.size
+        self.exchange = exchange
+        if exchange == "none":
+            # mirrored shard: nothing is sent, nothing arrives, no collective
+            if send_rows.size:
+                raise ValueError("exchange='none' needs a mirrored shard (the handle was built "
+                                 "with CFS_HIP_FLAG_SHARD_EXCHANGE)")
+            self.nsend = self.nrecv = 0
+            self.send_buf = torch.zeros(1, dtype=tdt, device=device)
+            self.recv_buf = self.send_buf
+            return
         # 1) counts
         sc = torch.from_numpy(send_counts).to(cdev)
         rc = torch.zeros(nranks, dtype=torch.int64, device=cdev)
@@ -56,7 +78,6 @@ class ShardedSym:
         # equal (padded) blocks and ONE reduce-scatter(sum) hands each owner the sum
         # for its block.  Moves nranks*max_rows values per rank instead of the few
         # touched rows, so it is the slower option; kept selectable.
-        self.exchange = exchange
         if exchange == "reduce_scatter":
             if row_splits is None:
                 raise ValueError("reduce_scatter exchange needs row_splits")
@@ -92,13 +113,20 @@ class ShardedSym:
 
     def spmv(self, y_block, x):
         """y_block <- rows [row_begin,row_end) of A x; x is the full vector.
+        mirrored shard: tile kernel -> fold, no collective.  exchange forms:
         tile kernel -> pack -> [exchange || local fold] -> fold of what arrived"""
+        if self.exchange == "none":
+            self.A.spmv_phases(y_block, x, None, 1 | 2)
+            return
         self.A.spmv_phases(y_block, x, self.send_buf, 1 | 4)   # tiles + pack
         self.finish(y_block, x)
 
     def finish(self, y_block, x):
         """everything after tiles + pack: start the one collective of the path,
         fold the local strips while it is in flight, then fold what arrived"""
+        if self.exchange == "none":
+            self.A.spmv_phases(y_block, x, None, 2)            # local fold only
+            return
         if self.exchange == "reduce_scatter":
             return self._finish_reduce_scatter(y_block, x)
         if self.stage:
@@ -135,3 +163,43 @@ class ShardedSym:
         if work is not None:
             work.wait()
         y_block += self.rs_out[:y_block.numel()]
+
+
+def build_shard(n, rowptr, colind, values, nranks, rank, row_splits, device, options=None,
+                exchange="none", pg=None, stage_via_host=False):
+    """Build this rank's row block and its ShardedSym.  exchange="none" asks for a
+    mirrored shard; a matrix whose off-block structure cannot be mirrored
+    (structurally unsymmetric or duplicate entries) makes SOME rank fail, so the
+    ranks agree (one all-reduce at set-up) and all fall back to "all_to_all".
+    Returns (SymMatrix, ShardedSym, exchange actually used)."""
+    import torch
+    import torch.distributed as dist
+    from . import matrix as M
+    from ._lib import CfsHipError, Options
+    flags = options.flags if options is not None else 0
+    base = (options.max_slots, options.max_tile_nnz, options.block_threads) if options is not None \
+        else (0, 0, 0)
+    dtype = np.asarray(values).dtype
+    A = None
+    if exchange == "none":
+        ok = 1
+        try:
+            A = M.SymMatrix(n, rowptr, colind, values, options=Options(*base, flags & ~M.FLAG_SHARD_EXCHANGE),
+                            row_splits=row_splits, rank=rank)
+        except CfsHipError as e:
+            if "mirror" not in str(e):
+                raise
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32,
+                            device=torch.device("cpu") if stage_via_host else device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=pg)
+        if int(flag.item()) == 0:
+            if A is not None:
+                A.close()
+            A, exchange = None, "all_to_all"
+    if A is None:
+        A = M.SymMatrix(n, rowptr, colind, values, options=Options(*base, flags | M.FLAG_SHARD_EXCHANGE),
+                        row_splits=row_splits, rank=rank)
+    sh = ShardedSym(A, nranks, rank, dtype, device, pg=pg, stage_via_host=stage_via_host,
+                    exchange=exchange, row_splits=row_splits)
+    return A, sh, exchange

@@ -51,6 +51,9 @@ def _stream_ptr(stream=None):
     return s.cuda_stream
 
 
+FLAG_SHARD_EXCHANGE = 64  # include/cfs_hip.h: CFS_HIP_FLAG_SHARD_EXCHANGE
+
+
 def make_options(max_slots=0, max_tile_nnz=0, block_threads=0, flags=0):
     return _lib.Options(max_slots, max_tile_nnz, block_threads, flags)
 
@@ -79,8 +82,14 @@ def plan_check(n, rowptr, colind, values, nranks=1, rank=0, row_splits=None, opt
 
 
 def plan_send_info(n, rowptr, colind, values, nranks, rank, row_splits, options=None):
-    """host-only (send_counts, send_rows) of one shard -- for the CPU exchange tests"""
+    """host-only (send_counts, send_rows) of one shard in the EXCHANGE form
+    (CFS_HIP_FLAG_SHARD_EXCHANGE) -- for the CPU exchange tests"""
     lib = _lib.load()
+    if options is None:
+        options = make_options(flags=FLAG_SHARD_EXCHANGE)
+    else:
+        options = _lib.Options(options.max_slots, options.max_tile_nnz, options.block_threads,
+                               options.flags | FLAG_SHARD_EXCHANGE)
     rowptr, colind = _np_i32(rowptr), _np_i32(colind)
     values = np.ascontiguousarray(values, dtype=np.float64)
     rs = _np_i32(row_splits)

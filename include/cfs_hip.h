@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CFS_HIP_ABI_VERSION 1
+#define CFS_HIP_ABI_VERSION 2
 
 /* error codes */
 #define CFS_HIP_OK 0
@@ -88,6 +88,13 @@ typedef struct {
  * rows with per-XCD work shares (kept only if the launches end earlier; only
  * for matrices with >= 2M stored nonzeros).  This flag skips that step.       */
 #define CFS_HIP_FLAG_NO_CALIBRATE 32
+/* Shards only.  Default: off-block entries are MIRRORED -- stored by both ranks
+ * they touch and processed one-sided, so that no contribution to y ever leaves
+ * the rank and a sharded SpMV needs no exchange (x is replicated anyway; the
+ * duplicated boundary entries are a few per cent of a shard).  With this flag a
+ * shard keeps its off-block entries two-sided and packs its contributions to
+ * rows of lower ranks for an all-to-all / reduce-scatter (the exchange form). */
+#define CFS_HIP_FLAG_SHARD_EXCHANGE 64
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->
@@ -189,6 +196,8 @@ typedef struct {
    * slots + per-row metadata + x/y + halo strips + fold index)           */
   int64_t bytes_streamed;
   int64_t device_bytes; /* device memory held by the handle               */
+  int64_t mirror_entries; /* one-sided entries a mirrored shard stores for rows of
+                             higher ranks (0 for a whole matrix / exchange form)  */
 } cfs_hip_sym_stats;
 int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out);
 /* developer diagnostic: one extra launch of the tile kernel that records, per
@@ -212,6 +221,7 @@ typedef struct {
   int64_t nslices, halo_slots, stream_len, nnz_low, fold_rows, remote_vals;
   int64_t decoded;    /* triples recovered from the device format           */
   int64_t mismatches; /* 0 = the schedule encodes exactly the input         */
+  int64_t mirror_entries; /* mirrored off-block entries (shards, default form)  */
 } cfs_hip_plan_report;
 int cfs_hip_sym_plan_check_f64(int n, const int *rowptr, const int *colind,
                                const double *values, int nranks, int rank,

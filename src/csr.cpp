@@ -7,6 +7,7 @@
 //                            then frees the full CSR like compress_symmetry (:1700-1706)
 // multiply    ~ spmv_fn   -> cfs_hip_sym_spmv / cfs_hip_csr_spmv
 #include <cstdlib>
+#include <cstring>
 #include <iostream>
 #include <type_traits>
 
@@ -100,7 +101,7 @@ template <typename IndexT, typename ValueT> size_t CSRMatrix<IndexT, ValueT>::si
 }
 
 template <typename IndexT, typename ValueT>
-bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning) {
+bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning t) {
   if (tuned_) return true;
   static_assert(std::is_same<IndexT, int>::value, "int indices only (src/csr.cpp:10-11)");
   int rc;
@@ -110,10 +111,15 @@ bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning) {
     std::cout << "[INFO]: compressing for symmetry: MI355X tile schedule" << std::endl;
 #endif
     cfs_hip_sym_t h = nullptr;
+    // Tuning::Aggressive (the default, as in the reference) also measures the XCDs
+    // and re-cuts the rows; Tuning::None builds the schedule once
+    cfs_hip_options opt;
+    memset(&opt, 0, sizeof opt);
+    if (t == Tuning::None) opt.flags |= CFS_HIP_FLAG_NO_CALIBRATE;
     if (std::is_same<ValueT, double>::value)
-      rc = cfs_hip_sym_create_f64(nrows_, rowptr_, colind_, (const double *)values_, nullptr, &h);
+      rc = cfs_hip_sym_create_f64(nrows_, rowptr_, colind_, (const double *)values_, &opt, &h);
     else
-      rc = cfs_hip_sym_create_f32(nrows_, rowptr_, colind_, (const float *)values_, nullptr, &h);
+      rc = cfs_hip_sym_create_f32(nrows_, rowptr_, colind_, (const float *)values_, &opt, &h);
     if (rc == CFS_HIP_ERR_UNSUPPORTED) {
       // a row with more stored columns than an LDS window holds: the symmetric
       // schedule does not apply; the full CSR is still here, so the general HIP

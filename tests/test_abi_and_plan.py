@@ -22,7 +22,7 @@ def header_symbols():
 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = cfs.load()
-    assert lib.cfs_hip_abi_version() == 1
+    assert lib.cfs_hip_abi_version() == 2
     syms = header_symbols()
     assert len(syms) >= 30
     for name in syms:
@@ -124,10 +124,18 @@ def test_shard_schedules(nranks):
     rs = cfs.balanced_splits(n, rp, ci, nranks)
     assert rs[0] == 0 and rs[-1] == n and np.all(np.diff(rs) >= 0)
     assert all(int(v) % 16 == 0 for v in rs[1:-1])  # BlkFactor alignment, csr_matrix.tpp:418
-    tot, sent = 0, 0
+    tot, sent, mirrored, offblock_low = 0, 0, 0, 0
+    xopt = cfs.make_options(flags=cfs.FLAG_SHARD_EXCHANGE)
     for r in range(nranks):
+        # default form: off-block entries mirrored, nothing to send
         rep = cfs.plan_check(n, rp, ci, va, nranks, r, rs)
-        assert rep["mismatches"] == 0
+        assert rep["mismatches"] == 0 and rep["remote_vals"] == 0
+        mirrored += rep["mirror_entries"]
+        lo = np.repeat(np.arange(n), np.diff(rp))
+        offblock_low += int(np.sum((lo >= rs[r]) & (lo < rs[r + 1]) & (ci < rs[r])))
+        # exchange form: contributions to lower ranks are packed
+        rep = cfs.plan_check(n, rp, ci, va, nranks, r, rs, options=xopt)
+        assert rep["mismatches"] == 0 and rep["mirror_entries"] == 0
         tot += rep["nnz_low"]
         counts, rows = cfs.plan_send_info(n, rp, ci, va, nranks, r, rs)
         assert counts.sum() == rows.size == rep["remote_vals"]
@@ -135,6 +143,8 @@ def test_shard_schedules(nranks):
         assert np.all(rows < rs[r]) and np.all(np.diff(rows) > 0)
         sent += rows.size
     assert tot == low
+    # every off-block lower entry is stored a second time by the rank that owns its column
+    assert mirrored == offblock_low > 0
     # nnz balance within 10 %
     per = [cfs.plan_check(n, rp, ci, va, nranks, r, rs)["nnz_low"] for r in range(nranks)]
     assert max(per) <= 1.1 * (low / nranks) + 1000

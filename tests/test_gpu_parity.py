@@ -164,7 +164,9 @@ def test_shards_on_one_device(nranks, dtype):
     rs = cfs.balanced_splits(n, rp, ci, nranks)
     xd = torch.from_numpy(x).cuda()
     tdt = xd.dtype
-    shards = [cfs.SymMatrix(n, rp, ci, va, row_splits=rs, rank=r) for r in range(nranks)]
+    xopt = cfs.make_options(flags=cfs.FLAG_SHARD_EXCHANGE)  # the exchange form of a shard
+    shards = [cfs.SymMatrix(n, rp, ci, va, options=xopt, row_splits=rs, rank=r)
+              for r in range(nranks)]
     send_rows = [s.send_rows() for s in shards]
     send_counts = [s.send_counts() for s in shards]
     # receive lists: concatenation by source rank of the rows aimed at me
@@ -240,6 +242,43 @@ def test_natural_and_clustered_orders_agree():
     y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
     assert scaled_err(ys[0], y_ld, absrow) <= 1e-12 and scaled_err(ys[1], y_ld, absrow) <= 1e-12
     assert scaled_err(ys[0], ys[1], absrow) <= 1e-13
+
+
+@pytest.mark.parametrize("name,scale,nranks,flags", [
+    ("Flan_1565", 0.02, 2, 0), ("Flan_1565", 0.02, 4, 0), ("Flan_1565", 0.05, 3, 8),
+    ("ldoor", 0.03, 4, 0), ("pwtk", 0.1, 8, 0)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_mirrored_shards_need_no_exchange(name, scale, nranks, flags, dtype):
+    """default form of a shard: off-block entries are stored by both ranks they touch
+    and processed one-sided -- every rank's block of y is complete after its own
+    local launches, nothing is packed, sent or received"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from oracle import oracle
+    torch = _torch()
+    n, rp, ci, va, low = synth.generate(name, scale)
+    va = va.astype(dtype)
+    x = synth.make_x(n, 42, dtype)
+    rs = cfs.balanced_splits(n, rp, ci, nranks)
+    xd = torch.from_numpy(x).cuda()
+    y = np.zeros(n, dtype=dtype)
+    mirrored = 0
+    for r in range(nranks):
+        A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=flags), row_splits=rs, rank=r)
+        st = A.stats()
+        assert st["remote_vals"] == 0 and A.send_rows().size == 0
+        mirrored += st["mirror_entries"]
+        yb = torch.full((int(rs[r + 1] - rs[r]),), float("nan"), dtype=xd.dtype, device="cuda")
+        A.spmv_phases(yb, xd, None, 7)
+        torch.cuda.synchronize()
+        y[rs[r]:rs[r + 1]] = yb.cpu().numpy()
+        A.close()
+    rows_of = np.repeat(np.arange(n), np.diff(rp))
+    owner = np.searchsorted(rs, rows_of, side="right") - 1
+    col_owner = np.searchsorted(rs, ci, side="right") - 1
+    assert mirrored == int(np.sum(col_owner < owner)) > 0  # each off-block lower entry once more
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
 
 
 def test_cg_solver_loop_on_the_gpu():
