@@ -945,6 +945,27 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   const int rb = row_splits_in ? row_splits_in[rank] : 0;
   const int re = row_splits_in ? row_splits_in[rank + 1] : n;
   const int rows = re - rb;
+  if (opt.mirror_offblock && nranks > 1 && rb >= 0 && re <= n && rb <= re) {
+    // A mirrored shard finds the entries (r, c) of higher ranks' rows r through
+    // their mirror images (c, r) in its OWN rows.  Every such image is matched
+    // to its lower entry when the streams are filled; equal counts then make the
+    // match a bijection.  A structurally unsymmetric matrix is refused here
+    // (the exchange form reads the lower triangle only and takes it).
+    int64_t up = 0, low_in = 0;
+#pragma omp parallel for schedule(static) reduction(+ : up) num_threads(host_threads())
+    for (int i = rb; i < re; i++)
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+        if (colind[j] >= re) up++;
+#pragma omp parallel for schedule(static) reduction(+ : low_in) num_threads(host_threads())
+    for (int r = re; r < n; r++)
+      for (int j = rowptr[r]; j < rowptr[r + 1]; j++)
+        if (colind[j] >= rb && colind[j] < re) low_in++;
+    if (up != low_in) {
+      P = SymPlan<V>();
+      P.error = "mirror: structurally unsymmetric off-block entries";
+      return false;
+    }
+  }
   if (!opt.reorder || opt.force_order == 1 || rb < 0 || re > n || rows < 256)
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
                               nullptr, nullptr, P);
@@ -1044,6 +1065,17 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
         q++;
       }
     }
+  }
+  if (!asym) {
+    // every stored entry of the block must have landed on exactly one schedule row:
+    // a lower entry whose upper image is missing (structurally unsymmetric input)
+    // is lost when its column comes later in the schedule than its row
+    int64_t want = 0;
+#pragma omp parallel for schedule(static) reduction(+ : want) num_threads(host_threads())
+    for (int i = rb; i < re; i++)
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+        if (colind[j] <= i || (mirror && colind[j] >= re)) want++;
+    if (want != bnnz) asym = true;
   }
   if (asym)
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,

@@ -106,7 +106,12 @@ typedef struct {
  * col <= row are read; a missing diagonal entry counts as 0.
  *
  * The *_shard_* forms build rank `rank`'s 1-D row block of a matrix sharded
- * over `nranks` GPUs at row boundaries row_splits[0..nranks].    */
+ * over `nranks` GPUs at row boundaries row_splits[0..nranks].  By
+ * default the shard is MIRRORED (see CFS_HIP_FLAG_SHARD_EXCHANGE): it also reads
+ * the entries of its rows right of the block and the lower entries (c, i) they
+ * mirror, its SpMV needs no exchange, and a matrix whose off-block structure is
+ * not symmetric (or has duplicate entries there) is refused with an error whose
+ * message starts with "mirror:" -- build it with CFS_HIP_FLAG_SHARD_EXCHANGE.   */
 int cfs_hip_sym_create_f64(int n, const int *rowptr, const int *colind,
                            const double *values, const cfs_hip_options *opt,
                            cfs_hip_sym_t *out);

@@ -182,3 +182,44 @@ def test_duplicates_and_unsymmetric_structure_keep_natural_order():
     rep = cfs.plan_check(n, rp2, cols[keep].astype(np.int32), vals[keep],
                          options=cfs.make_options(flags=16))
     assert rep["mismatches"] == 0
+    # no duplicates at all, only missing upper images (every 7th): an entry whose
+    # column comes later in the clustered schedule than its row would be lost
+    A = (L + L.T + sp.diags(np.full(n, 3.0))).tocsr()
+    A.sort_indices()
+    ar = np.repeat(np.arange(n), np.diff(A.indptr))
+    up = np.flatnonzero(A.indices > ar)[::7]
+    A.data[up] = 0
+    A.eliminate_zeros()
+    rep = cfs.plan_check(n, A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data,
+                         options=cfs.make_options(flags=16))
+    assert rep["mismatches"] == 0 and rep["decoded"] == L.nnz
+
+
+def test_mirrored_shard_refuses_unsymmetric_offblock_structure():
+    """a mirrored shard finds the entries of higher ranks' rows through their images in
+    its own rows: a missing image (either way) must be an error, never a silent loss;
+    the exchange form reads the lower triangle only and takes the matrix"""
+    import scipy.sparse as sp
+    n, rp, ci, va, _ = synth.generate("pwtk", 0.02)
+    rs = cfs.balanced_splits(n, rp, ci, 2)
+    A = sp.csr_matrix((va, ci, rp), shape=(n, n)).tolil()
+    cut = int(rs[1])
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    k = int(np.flatnonzero((rows >= cut) & (ci < cut))[0])   # a lower entry across the cut
+    r, c = int(rows[k]), int(ci[k])
+    for drop in ((c, r), (r, c)):                              # its image / the entry itself
+        B = A.copy()
+        B[drop[0], drop[1]] = 0
+        B = B.tocsr()
+        B.eliminate_zeros()
+        B.sort_indices()
+        args = (n, B.indptr.astype(np.int32), B.indices.astype(np.int32), B.data)
+        # the rank that owns the column side of the cut entry notices; dist.build_shard
+        # makes all ranks agree and fall back to the exchange form
+        with pytest.raises(_lib.CfsHipError, match="mirror"):
+            cfs.plan_check(*args, 2, 0, rs)
+        assert cfs.plan_check(*args, 2, 1, rs)["mismatches"] == 0
+        for rank in (0, 1):
+            rep = cfs.plan_check(*args, 2, rank, rs,
+                                 options=cfs.make_options(flags=cfs.FLAG_SHARD_EXCHANGE))
+            assert rep["mismatches"] == 0

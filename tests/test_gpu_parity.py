@@ -301,3 +301,86 @@ def test_cg_solver_loop_on_the_gpu():
     assert 0 < it < 500 and res <= 1e-10
     assert np.max(np.abs(u.cpu().numpy() - u_ref)) <= 1e-9 * np.max(np.abs(u_ref))
     A.close()
+
+
+def _fallback_worker(rank, world, port, q):
+    try:
+        import os, sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, root)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import scipy.sparse as sp
+        import torch
+        import torch.distributed as dist
+        import cfs_spmv_amd as cfs
+        from cfs_spmv_amd import synth
+        from cfs_spmv_amd.dist import build_shard
+        from oracle import oracle
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n, rp, ci, va, _ = synth.generate("pwtk", 0.03)
+        rs = cfs.balanced_splits(n, rp, ci, world)
+        res = []
+        for broken in (False, True):
+            if broken:  # drop the upper image of one lower entry across the cut
+                rows = np.repeat(np.arange(n), np.diff(rp))
+                k = int(np.flatnonzero((rows >= rs[1]) & (ci < rs[1]))[0])
+                A = sp.csr_matrix((va, ci, rp), shape=(n, n)).tolil()
+                A[int(ci[k]), int(rows[k])] = 0
+                A = A.tocsr()
+                A.eliminate_zeros()
+                A.sort_indices()
+                rp2, ci2, va2 = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+            else:
+                rp2, ci2, va2 = rp, ci, va
+            M, sh, used = build_shard(n, rp2, ci2, va2, world, rank, rs, torch.device("cuda", 0),
+                                      exchange="none", stage_via_host=True)
+            x = synth.make_x(n)
+            xd = torch.from_numpy(x).cuda()
+            yb = torch.full((int(rs[rank + 1] - rs[rank]),), float("nan"), dtype=torch.float64,
+                            device="cuda")
+            sh.spmv(yb, xd)
+            torch.cuda.synchronize()
+            # the reference semantics: the LOWER triangle defines the operator
+            L = sp.tril(sp.csr_matrix((va2, ci2, rp2), shape=(n, n)), -1)
+            S = (L + L.T + sp.diags(sp.csr_matrix((va2, ci2, rp2), shape=(n, n)).diagonal())).tocsr()
+            S.sort_indices()
+            y_ld, absrow = oracle.csr_spmv_ld(n, S.indptr.astype(np.int32),
+                                              S.indices.astype(np.int32), S.data, x)
+            sl = slice(int(rs[rank]), int(rs[rank + 1]))
+            err = float(np.max(np.abs(yb.cpu().numpy() - y_ld[sl]) /
+                               np.maximum(np.abs(y_ld[sl]), absrow[sl])))
+            res.append((used, err))
+            M.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, res))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, f"{e}\n{traceback.format_exc()}"))
+
+
+def test_build_shard_forms_agree_across_ranks():
+    """two ranks sharing cuda:0 over gloo: a mirrorable matrix runs without exchange; one
+    whose off-block structure is unsymmetric makes rank 0 fail to mirror, and BOTH ranks
+    fall back to the exchange form together -- with the right answer either way"""
+    import socket
+    import torch.multiprocessing as mp
+    _torch()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, res in out:
+        assert not isinstance(res, str), f"rank {rank}: {res}"
+        (used0, err0), (used1, err1) = res
+        assert used0 == "none" and used1 == "all_to_all", res
+        assert err0 <= 1e-12 and err1 <= 1e-12, res
