@@ -1101,6 +1101,13 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     if (!c_ok) use_clustered = false;
     else if (n_ok && (sizeof(V) == 8 ? 2 * N.nhalo <= 5 * C.nhalo : N.nhalo <= 6 * C.nhalo))
       use_clustered = false;
+    // ... and only if the natural order is LDS-bound into more tiles than the
+    // clustered one.  When a group's rows fit one window either way, clustering
+    // still cuts the halo ~3x but loses (measured, Flan stand-in fp64: 1/8 shards
+    // 25.1 vs 23.4 us per SpMV, 1/2 shards 66.6 vs 64.9 us) -- while the whole
+    // matrix, 2 natural tiles per group against 1 clustered, gains 7 %.
+    else if (n_ok && N.tiles.size() <= C.tiles.size())
+      use_clustered = false;
   }
   if (use_clustered &&
       build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in, opt,
