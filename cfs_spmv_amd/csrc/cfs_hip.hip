@@ -182,7 +182,7 @@ __device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigne
 // as a result path): 1 = no transposed LDS atomics, 2 = no LDS traffic at all,
 // 3 = windows only (no matrix stream), 4 = matrix stream only (no windows).
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int MODE, bool NT, bool OFFB>
+template <typename V, int BLOCK, int MODE, bool NT, bool OFFB, int U>
 __global__ void __launch_bounds__(BLOCK)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const Tile *__restrict__ a_gfirst,
                         const int32_t *__restrict__ a_group_ptr,
@@ -241,7 +241,11 @@ __global__ void __launch_bounds__(BLOCK)
   // system a round trip costs microseconds, so the window of the NEXT tile is
   // requested before the barrier that ends the current tile's slices and lands
   // while the y window is flushed.
-  constexpr int U = cfs_plan::kSlotsPerThread;
+  // U = LDS slots one thread fills / flushes.  Every thread issues all U gathers
+  // (clamped, unconditional), so a launch whose windows are small uses the
+  // instantiation with the smallest U that covers them: a tile with 1 100 slots
+  // would otherwise issue 78 % of its start-up loads for nothing.
+  static_assert(U <= cfs_plan::kSlotsPerThread, "U");
   V xr[U];
   bool first_gather = true;
   auto gather_x = [&](const Tile &tn) {
@@ -723,52 +727,50 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     return raise_lds_limit();
   }
 
-  template <int BLOCK, int MODE, bool NT> int raise_attr() {
-    HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, MODE, NT, false>,
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    if (MODE == 0)
-      HIPCHK(hipFuncSetAttribute((const void *)cfs_sym_tile_kernel<V, BLOCK, 0, NT, true>,
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    return 0;
+  // the instantiation of the tile kernel this handle launches
+  template <int BLOCK> static const void *pick_kernel(int mode, bool nt, bool offb, int u) {
+#define CFS_K(M, N, O, UU) ((const void *)cfs_sym_tile_kernel<V, BLOCK, M, N, O, UU>)
+    constexpr int UM = cfs_plan::kSlotsPerThread;
+    switch (mode) {
+    case 1: return CFS_K(1, true, false, UM);
+    case 2: return CFS_K(2, true, false, UM);
+    case 3: return CFS_K(3, true, false, UM);
+    case 4: return CFS_K(4, true, false, UM);
+    default: break;
+    }
+    static const void *const tab[2][2][3] = {
+        {{CFS_K(0, false, false, 3), CFS_K(0, false, false, 6), CFS_K(0, false, false, UM)},
+         {CFS_K(0, false, true, 3), CFS_K(0, false, true, 6), CFS_K(0, false, true, UM)}},
+        {{CFS_K(0, true, false, 3), CFS_K(0, true, false, 6), CFS_K(0, true, false, UM)},
+         {CFS_K(0, true, true, 3), CFS_K(0, true, true, 6), CFS_K(0, true, true, UM)}}};
+#undef CFS_K
+    return tab[nt ? 1 : 0][offb ? 1 : 0][u <= 3 ? 0 : (u <= 6 ? 1 : 2)];
   }
-  template <int BLOCK> int raise_one() {
-    int rc;
-    if ((rc = raise_attr<BLOCK, 0, true>()) || (rc = raise_attr<BLOCK, 0, false>()) ||
-        (rc = raise_attr<BLOCK, 1, true>()) || (rc = raise_attr<BLOCK, 2, true>()) ||
-        (rc = raise_attr<BLOCK, 3, true>()) || (rc = raise_attr<BLOCK, 4, true>()))
-      return rc;
-    return 0;
-  }
-  int raise_lds_limit() {
+  const void *tile_kernel() {
+    const int u = (P.lds_slots + P.block_threads - 1) / P.block_threads;
     switch (P.block_threads) {
-    case 256: return raise_one<256>();
-    case 512: return raise_one<512>();
-    default: return raise_one<1024>();
+    case 256: return pick_kernel<256>(ablate_mode, nt_stream, offblock, u);
+    case 512: return pick_kernel<512>(ablate_mode, nt_stream, offblock, u);
+    default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u);
     }
   }
+  const void *raised = nullptr; // kernel whose dynamic-LDS limit has been raised
+  int raise_lds_limit() { return 0; } // done lazily per instantiation in launch_tiles
 
-  template <int BLOCK, int MODE, bool NT, bool OFFB = false>
-  void launch_one(V *y, const V *x, hipStream_t st) {
-    hipLaunchKernelGGL((cfs_sym_tile_kernel<V, BLOCK, MODE, NT, OFFB>), dim3(P.ngroups), dim3(BLOCK),
-                       lds_bytes, st, dev.tiles, dev.gfirst, dev.group_ptr, dev.slot_col, dev.rowinfo, dev.diag,
-                       dev.slice_meta, dev.vals, dev.slots, dev.cvals, dev.crows, dev.ccols,
-                       dev.strip, dev.row_begin, dev.lds_slots, x, y, dbg_buf);
-  }
-  template <int BLOCK> void launch_tiles(V *y, const V *x, hipStream_t st) {
-    switch (ablate_mode) {
-    case 1: launch_one<BLOCK, 1, true>(y, x, st); break;
-    case 2: launch_one<BLOCK, 2, true>(y, x, st); break;
-    case 3: launch_one<BLOCK, 3, true>(y, x, st); break;
-    case 4: launch_one<BLOCK, 4, true>(y, x, st); break;
-    default:
-      if (offblock) { // mirrored shard: one-sided off-block slots
-        if (nt_stream) launch_one<BLOCK, 0, true, true>(y, x, st);
-        else launch_one<BLOCK, 0, false, true>(y, x, st);
-      } else {
-        if (nt_stream) launch_one<BLOCK, 0, true>(y, x, st);
-        else launch_one<BLOCK, 0, false>(y, x, st);
-      }
+  int launch_tiles(V *y, const V *x, hipStream_t st) {
+    const void *k = tile_kernel();
+    if (k != raised) {
+      HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+      raised = k;
     }
+    void *args[] = {(void *)&dev.tiles, (void *)&dev.gfirst, (void *)&dev.group_ptr,
+                    (void *)&dev.slot_col, (void *)&dev.rowinfo, (void *)&dev.diag,
+                    (void *)&dev.slice_meta, (void *)&dev.vals, (void *)&dev.slots,
+                    (void *)&dev.cvals, (void *)&dev.crows, (void *)&dev.ccols,
+                    (void *)&dev.strip, (void *)&dev.row_begin, (void *)&dev.lds_slots,
+                    (void *)&x, (void *)&y, (void *)&dbg_buf};
+    HIPCHK(hipLaunchKernel(k, dim3(P.ngroups), dim3(P.block_threads), args, lds_bytes, st));
+    return 0;
   }
 
   int spmv_local(void *yv, const void *xv, void *sendv, hipStream_t st, int phases) override {
@@ -776,11 +778,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     const V *x = (const V *)xv;
     if (P.tiles.empty()) return 0;
     if (phases & CFS_HIP_PHASE_TILES) {
-      switch (P.block_threads) {
-      case 256: launch_tiles<256>(y, x, st); break;
-      case 512: launch_tiles<512>(y, x, st); break;
-      default: launch_tiles<1024>(y, x, st); break;
-      }
+      int rc = launch_tiles(y, x, st);
+      if (rc) return rc;
     }
     // pack first: the exchange of a shard can then start while the local fold runs
     if ((phases & CFS_HIP_PHASE_PACK) && nsend > 0) {
@@ -987,7 +986,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
 // resident wave of workgroups (a workgroup that has to wait for a slot would
 // run as a second round and double the launch time)
 template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
-  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true, true>;
+  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true, true, cfs_plan::kSlotsPerThread>;
   HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k, BLOCK, lds));
   return 0;
