@@ -65,7 +65,10 @@ def build_cxx(force=False):
     """libsparse.so + bench_spmv_mmf + test_spmv_mmf (the reference's products)"""
     if force:
         _run(["make", "-C", ROOT, "clean"])
+        _run(["make", "-C", ROOT, "clean", "BUILD=build_sp"])
     _run(["make", "-C", ROOT, "DP=1"])
+    # the reference's default configure is single precision (the Queen_4147 config)
+    _run(["make", "-C", ROOT, "BUILD=build_sp"])
     return os.path.join(ROOT, "build", "libsparse.so")
 
 

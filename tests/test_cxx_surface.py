@@ -107,6 +107,10 @@ def test_drivers_end_to_end(tmp_path):
                   r"gflops/s: (\S+) threads: (\d+) size\(MB\): (\S+)", r.stdout)
     assert m, r.stdout
     assert float(m.group(3)) > 0
+    # the single-precision build of the same driver (the reference's default configure)
+    r = subprocess.run([os.path.join(ROOT, "build_sp", "bench_spmv_mmf"), p, "1", "64"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "format: SSS" in r.stdout, r.stdout + r.stderr
     # general file through Format::sss: silent fall-back to CSR (csr_matrix.tpp:13-19)
     g = str(tmp_path / "gen.mtx")
     synth.write_mtx(g, n, rp, ci, va, general=True)
