@@ -57,6 +57,7 @@ template <typename V> struct SymDev {
   const uint32_t *rowinfo;
   const V *diag;
   const uint4 *slice_meta; // {value offset, slot offset | lanes of packet 0 << 25, leader mask}
+  const uint8_t *leadlane; // per slice and lane: the lane whose slots it reads
   const V *vals;
   const uint16_t *slots;
   const V *cvals; // COO leftovers (len % 4 per row): value, row slot, column slot
@@ -77,12 +78,17 @@ template <typename V> struct Pkt {
   ushort4 c;
 };
 
-// `leaders` (one bit per lane of the slice): lanes whose whole slot sequence
-// repeats the lane before them store no slots; every lane reads the slots of
-// the last leader at or below it (rank among the leaders = position in the
-// packet's slot block).
-__device__ __forceinline__ int leader_rank(unsigned long long leaders, int l) {
-  return __popcll(leaders & (~0ull >> (63 - l))) - 1;
+// `leaders` (one bit per lane of the slice): a lane whose slot sequence is a
+// prefix of an earlier lane's stores no slots and reads that LEADER lane's
+// (cfs_plan::SymPlan::leadlane, one byte per lane).  A leader's block inside a
+// packet's slot block is its rank among the leaders: lanes are sorted by packet
+// count, so every leader below it is active whenever it is.
+__device__ __forceinline__ int leader_rank(unsigned long long leaders, int leader_lane) {
+  return __popcll(leaders & ((1ull << leader_lane) - 1ull));
+}
+// leaders among the cnt active lanes of a packet
+__device__ __forceinline__ int active_leaders(unsigned long long leaders, int cnt) {
+  return cnt > 0 ? __popcll(leaders & (~0ull >> (64 - cnt))) : 0;
 }
 // A matrix stream larger than the 256 MiB Infinity Cache is read exactly once
 // per SpMV: its loads then carry the non-temporal hint (NT) so that they do not
@@ -97,32 +103,36 @@ template <bool NT, typename T> __device__ __forceinline__ T stream_load(const T 
   if (NT) return __builtin_nontemporal_load(p);
   return *p;
 }
+// lrank = rank of this lane's leader; a lane past the packet's end is clamped to
+// the last stored block (same cache lines, bytes unused)
 template <bool NT>
 __device__ __forceinline__ void fetch_packet(Pkt<double> &p, const double *tv,
                                              const uint16_t *ts, uint32_t off, uint32_t soff,
-                                             int cnt, unsigned long long leaders, int lane) {
+                                             int cnt, unsigned long long leaders, int lane,
+                                             int lrank) {
   const int ll = min(lane, max(cnt, 1) - 1);
+  const int rk = min(lrank, max(active_leaders(leaders, cnt), 1) - 1);
   const cfs_d2 lo = stream_load<NT>(reinterpret_cast<const cfs_d2 *>(tv + off + ll * 2));
   const cfs_d2 hi = stream_load<NT>(reinterpret_cast<const cfs_d2 *>(tv + off + 2 * cnt + ll * 2));
-  const cfs_us4 c =
-      stream_load<NT>(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
+  const cfs_us4 c = stream_load<NT>(reinterpret_cast<const cfs_us4 *>(ts + soff + rk * 4));
   p.c = make_ushort4(c.x, c.y, c.z, c.w);
   p.v[0] = lo.x; p.v[1] = lo.y; p.v[2] = hi.x; p.v[3] = hi.y;
 }
 template <bool NT>
 __device__ __forceinline__ void fetch_packet(Pkt<float> &p, const float *tv,
                                              const uint16_t *ts, uint32_t off, uint32_t soff,
-                                             int cnt, unsigned long long leaders, int lane) {
+                                             int cnt, unsigned long long leaders, int lane,
+                                             int lrank) {
   const int ll = min(lane, max(cnt, 1) - 1);
+  const int rk = min(lrank, max(active_leaders(leaders, cnt), 1) - 1);
   const cfs_f4 q = stream_load<NT>(reinterpret_cast<const cfs_f4 *>(tv + off + ll * 4));
-  const cfs_us4 c =
-      stream_load<NT>(reinterpret_cast<const cfs_us4 *>(ts + soff + leader_rank(leaders, ll) * 4));
+  const cfs_us4 c = stream_load<NT>(reinterpret_cast<const cfs_us4 *>(ts + soff + rk * 4));
   p.c = make_ushort4(c.x, c.y, c.z, c.w);
   p.v[0] = q.x; p.v[1] = q.y; p.v[2] = q.z; p.v[3] = q.w;
 }
 // entries of the packet's slot block = 4 x (leaders among its cnt lanes)
 __device__ __forceinline__ uint32_t slot_block(unsigned long long leaders, int cnt) {
-  return cnt > 0 ? 4u * (uint32_t)__popcll(leaders & (~0ull >> (64 - cnt))) : 0u;
+  return 4u * (uint32_t)active_leaders(leaders, cnt);
 }
 
 // one stored nonzero a = A[row][col(c)]: row side into the register
@@ -188,7 +198,8 @@ __global__ void __launch_bounds__(BLOCK)
                         const int32_t *__restrict__ a_group_ptr,
                         const int32_t *__restrict__ a_slot_col,
                         const uint32_t *__restrict__ a_rowinfo, const V *__restrict__ a_diag,
-                        const uint4 *__restrict__ a_slice_meta, const V *__restrict__ a_vals,
+                        const uint4 *__restrict__ a_slice_meta,
+                        const uint8_t *__restrict__ a_leadlane, const V *__restrict__ a_vals,
                         const uint16_t *__restrict__ a_slots, const V *__restrict__ a_cvals,
                         const uint16_t *__restrict__ a_crows,
                         const uint16_t *__restrict__ a_ccols, V *__restrict__ a_strip,
@@ -206,6 +217,7 @@ __global__ void __launch_bounds__(BLOCK)
     const uint32_t *__restrict__ rowinfo;
     const V *__restrict__ diag;
     const uint4 *__restrict__ slice_meta;
+    const uint8_t *__restrict__ leadlane;
     const V *__restrict__ vals;
     const uint16_t *__restrict__ slots;
     const V *__restrict__ cvals;
@@ -213,7 +225,7 @@ __global__ void __launch_bounds__(BLOCK)
     const uint16_t *__restrict__ ccols;
     V *__restrict__ strip;
     int row_begin, lds_slots;
-  } d = {a_tiles, a_gfirst, a_group_ptr, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_vals,
+  } d = {a_tiles, a_gfirst, a_group_ptr, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_leadlane, a_vals,
          a_slots, a_cvals, a_crows, a_ccols, a_strip, a_row_begin, a_lds_slots};
   // slice ticket counter of the current tile (16 B so the dynamic region below
   // stays 16-byte aligned)
@@ -291,6 +303,12 @@ __global__ void __launch_bounds__(BLOCK)
     const uint16_t *ts = d.slots + t.sl_off;
     const uint4 *smeta = d.slice_meta + t.slice_base;
     const int nsl = t.nslices;
+    // leader lanes of this wave's first two slices: requested before the window
+    // fill waits for the x gather, so that they are there when the head packet's
+    // slot address needs them (one byte per lane; padded, clamped)
+    const uint8_t *llp = d.leadlane + (size_t)t.slice_base * 64 + lane;
+    int L_c = llp[min(wave, max(nsl, 1) - 1) * 64];
+    int L_n = llp[min(wave + NW, max(nsl, 1) - 1) * 64];
 
     // fill both LDS windows.  A thread owns the same slot indices here and in the
     // flush at the end of the previous tile, so no barrier is needed between.
@@ -316,6 +334,7 @@ __global__ void __launch_bounds__(BLOCK)
     Pkt<V> N;
     N.v[0] = N.v[1] = N.v[2] = N.v[3] = V(0);
     N.c = make_ushort4(0, 0, 0, 0);
+    int lr_c = 0; // rank of this lane's leader in the current slice
     if (s < nsl) {
       meta_c = smeta[s];
       if (s_n < nsl) meta_n = smeta[s_n];
@@ -324,8 +343,10 @@ __global__ void __launch_bounds__(BLOCK)
       const V d0 = stream_load<NT>(d.diag + vrow0 + q0);
       info_c = p0 < nvr ? i0 : 0u;
       dg_c = p0 < nvr ? d0 : V(0);
-      fetch_packet<NT>(N, tv, ts, meta_c.x, meta_c.y & 0x1ffffffu, (int)(meta_c.y >> 25),
-                   ((unsigned long long)meta_c.w << 32) | meta_c.z, lane);
+      const unsigned long long lead0 = ((unsigned long long)meta_c.w << 32) | meta_c.z;
+      lr_c = leader_rank(lead0, L_c);
+      fetch_packet<NT>(N, tv, ts, meta_c.x, meta_c.y & 0x1ffffffu, (int)(meta_c.y >> 25), lead0,
+                       lane, lr_c);
     }
     const int ncp = (t.ncoo + 255) >> 8; // COO packets of this tile
     Pkt<V> C;
@@ -334,7 +355,7 @@ __global__ void __launch_bounds__(BLOCK)
     C.c = Cr;
     if (wave < ncp) {
       fetch_packet<NT>(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)wave * 256u,
-                   (uint32_t)wave * 256u, 64, ~0ull, lane);
+                       (uint32_t)wave * 256u, 64, ~0ull, lane, lane);
       {
         const cfs_us4 rr = stream_load<NT>(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + wave * 256 + lane * 4));
         Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
@@ -351,6 +372,7 @@ __global__ void __launch_bounds__(BLOCK)
       int cnt = (int)(meta_c.y >> 25);
       const unsigned long long leaders = ((unsigned long long)meta_c.w << 32) | meta_c.z;
       Pkt<V> A = N;
+      const int lr = lr_c; // leader rank of this lane in the current slice
       // ticket for the slice after next (its metadata is a scalar load that
       // lands long before it is needed)
       int s_nn = 0;
@@ -363,11 +385,14 @@ __global__ void __launch_bounds__(BLOCK)
         const V dn = stream_load<NT>(d.diag + vrow0 + qn);
         info_c = pn < nvr ? in_ : 0u;
         dg_c = pn < nvr ? dn : V(0);
-        fetch_packet<NT>(N, tv, ts, meta_n.x, meta_n.y & 0x1ffffffu, (int)(meta_n.y >> 25),
-                     ((unsigned long long)meta_n.w << 32) | meta_n.z, lane);
+        const unsigned long long lead_n = ((unsigned long long)meta_n.w << 32) | meta_n.z;
+        lr_c = leader_rank(lead_n, L_n); // L_n was requested a slice ago
+        fetch_packet<NT>(N, tv, ts, meta_n.x, meta_n.y & 0x1ffffffu, (int)(meta_n.y >> 25), lead_n,
+                         lane, lr_c);
       }
       meta_c = meta_n;
       if (s_nn < nsl) meta_n = smeta[s_nn];
+      L_n = llp[min(s_nn, nsl - 1) * 64]; // leader lanes of the slice after next
       const int s_cur = s;
       s = s_n;
       s_n = s_nn;
@@ -383,11 +408,11 @@ __global__ void __launch_bounds__(BLOCK)
       while (g + 2 < amax) { // steady state: two packets per trip, no copies
         const int cnt1 = __popcll(__ballot(a > g + 1));
         const uint32_t off1 = off + 4u * (uint32_t)cnt, soff1 = soff + slot_block(leaders, cnt);
-        fetch_packet<NT>(B, tv, ts, off1, soff1, cnt1, leaders, lane);
+        fetch_packet<NT>(B, tv, ts, off1, soff1, cnt1, leaders, lane, lr);
         if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
         const int cnt2 = __popcll(__ballot(a > g + 2));
         const uint32_t off2 = off1 + 4u * (uint32_t)cnt1, soff2 = soff1 + slot_block(leaders, cnt1);
-        fetch_packet<NT>(A, tv, ts, off2, soff2, cnt2, leaders, lane);
+        fetch_packet<NT>(A, tv, ts, off2, soff2, cnt2, leaders, lane, lr);
         if (a > g + 1) consume_packet<V, MODE, OFFB>(B, xl, yl, xi, acc, ny);
         g += 2;
         off = off2;
@@ -397,7 +422,7 @@ __global__ void __launch_bounds__(BLOCK)
       if (amax - g == 2) {
         const int cnt1 = __popcll(__ballot(a > g + 1));
         fetch_packet<NT>(B, tv, ts, off + 4u * (uint32_t)cnt, soff + slot_block(leaders, cnt), cnt1,
-                     leaders, lane);
+                         leaders, lane, lr);
         if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
         if (a > g + 1) consume_packet<V, MODE, OFFB>(B, xl, yl, xi, acc, ny);
       } else if (amax - g == 1) {
@@ -412,7 +437,7 @@ __global__ void __launch_bounds__(BLOCK)
       const ushort4 Qr = Cr;
       if (cp + NW < ncp) {
         fetch_packet<NT>(C, d.cvals + t.coo_off, d.ccols + t.coo_off, (uint32_t)(cp + NW) * 256u,
-                     (uint32_t)(cp + NW) * 256u, 64, ~0ull, lane);
+                         (uint32_t)(cp + NW) * 256u, 64, ~0ull, lane, lane);
         const cfs_us4 rr = stream_load<NT>(reinterpret_cast<const cfs_us4 *>(d.crows + t.coo_off + (cp + NW) * 256 + lane * 4));
         Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
       }
@@ -646,7 +671,7 @@ struct cfs_hip_sym_s {
 
 template <typename V> struct SymMatrix : cfs_hip_sym_s {
   SymPlan<V> P; // big arrays released after upload
-  DevBuf tiles, gfirst, group_ptr, slot_col, rowinfo, diag, slice_meta, vals, slots, strip;
+  DevBuf tiles, gfirst, group_ptr, slot_col, rowinfo, diag, slice_meta, leadlane, vals, slots, strip;
   DevBuf cvals, crows, ccols;
   DevBuf fold_rec, fold_idx, send_ptr, send_idx;
   DevBuf rfold_rec, rfold_idx;
@@ -671,6 +696,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(rowinfo, P.rowinfo)
     UP(diag, P.diag)
     UP(slice_meta, P.slice_meta)
+    UP(leadlane, P.leadlane)
     UP(cvals, P.cvals)
     UP(crows, P.crows)
     UP(ccols, P.ccols)
@@ -703,6 +729,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     dev.rowinfo = (const uint32_t *)rowinfo.p;
     dev.diag = (const V *)diag.p;
     dev.slice_meta = (const uint4 *)slice_meta.p;
+    dev.leadlane = (const uint8_t *)leadlane.p;
     dev.cvals = (const V *)cvals.p;
     dev.crows = (const uint16_t *)crows.p;
     dev.ccols = (const uint16_t *)ccols.p;
@@ -717,6 +744,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     // release the big host arrays; keep the small metadata
     std::vector<V>().swap(P.vals);
     std::vector<uint16_t>().swap(P.slots);
+    std::vector<uint8_t>().swap(P.leadlane);
     std::vector<V>().swap(P.cvals);
     std::vector<uint16_t>().swap(P.crows);
     std::vector<uint16_t>().swap(P.ccols);
@@ -765,7 +793,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     }
     void *args[] = {(void *)&dev.tiles, (void *)&dev.gfirst, (void *)&dev.group_ptr,
                     (void *)&dev.slot_col, (void *)&dev.rowinfo, (void *)&dev.diag,
-                    (void *)&dev.slice_meta, (void *)&dev.vals, (void *)&dev.slots,
+                    (void *)&dev.slice_meta, (void *)&dev.leadlane, (void *)&dev.vals,
+                    (void *)&dev.slots,
                     (void *)&dev.cvals, (void *)&dev.crows, (void *)&dev.ccols,
                     (void *)&dev.strip, (void *)&dev.row_begin, (void *)&dev.lds_slots,
                     (void *)&x, (void *)&y, (void *)&dbg_buf};
@@ -847,7 +876,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
                         + (int64_t)(nfold + nsend) * (8 + 2 * s) + nslices * 16 +
                         (int64_t)P.tiles.size() * (int64_t)sizeof(Tile);
     o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + slot_col.bytes +
-                                rowinfo.bytes + diag.bytes + slice_meta.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +
+                                rowinfo.bytes + diag.bytes + slice_meta.bytes + leadlane.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +
                                 slots.bytes + strip.bytes + fold_rec.bytes +
                                 fold_idx.bytes + send_ptr.bytes + send_idx.bytes);
   }

@@ -92,7 +92,8 @@ static_assert(sizeof(Tile) == 64, "Tile must stay 64 bytes");
 struct SliceMeta {
   uint32_t voff;      // entry offset of the slice's first packet in the tile's value stream
   uint32_t soff_cnt0; // bits 0..24: offset in the tile's slot stream; bits 25..31: lanes of packet 0
-  uint64_t leaders;   // bit l = lane l stores its own slots; 0 = it repeats lane l-1's
+  uint64_t leaders;   // bit l = lane l stores its own slots (a LEADER); the others read the
+                      // slots of the leader lane named in SymPlan::leadlane
 };
 static_assert(sizeof(SliceMeta) == 16, "SliceMeta must stay 16 bytes");
 
@@ -153,6 +154,7 @@ template <typename V> struct SymPlan {
   std::vector<SliceMeta> slice_meta; // [S]
   std::vector<V> vals;              // [stream_len + pad] packet stream
   std::vector<uint16_t> slots;      // [slot_len + pad]: only the leader lanes' slots
+  std::vector<uint8_t> leadlane;    // [S * 64 + pad] lane -> its leader lane in the slice
   int64_t slot_len = 0;
   std::vector<V> cvals;             // [coo_len] COO leftovers, packet layout
   std::vector<uint16_t> crows, ccols; // [coo_len]
@@ -292,7 +294,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   };
 
   // ---- lower counts -----------------------------------------------------
-  std::vector<int32_t> lcnt(rows, 0);
+  std::vector<int32_t> lcnt(rows, 0), firstcol(rows, -1);
   int64_t nnz_low = 0, nnz_diag = 0, nnz_mirror = 0, mirror_dup = 0;
 #pragma omp parallel for schedule(static) reduction(+ : nnz_low, nnz_diag, nnz_mirror, mirror_dup) num_threads(host_threads())
   for (int i = rb; i < re; i++) {
@@ -308,6 +310,12 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
       }
     }
     lcnt[i - rb] = c + up;
+    {
+      int fc = -1; // first stored column: rows of one mesh node share it (sibling test)
+      for (int j = rowptr[i]; j < rowptr[i + 1] && fc < 0; j++)
+        if (stored(i, colind[j])) fc = colind[j];
+      firstcol[i - rb] = fc;
+    }
     nnz_low += c;
     nnz_mirror += up;
     if (dup) mirror_dup++;
@@ -477,28 +485,62 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     for (int r = 0; r < t.nown; r++) sum += lcnt[t.row0 - rb + r] >> 2;
     const int avg = (int)((sum + t.nown - 1) / std::max(1, (int)t.nown));
     const int acap = std::max(8, 2 * avg);
+    // SIBLINGS stay together: consecutive rows with the same first stored column
+    // (the rows of one mesh node: their column sequences are prefixes of one
+    // another) form a group; groups are sorted by their longest member
+    // (stable counting sort, descending), slices are cut from that order and
+    // only then sorted by packet count inside each slice.  A sibling with fewer
+    // packets can then name a longer one IN ITS SLICE as its slot leader.
+    struct Grp {
+      int32_t first, count, key; // range in tmp, max packets of a member
+    };
     std::vector<VRow> tmp;
+    std::vector<Grp> grp;
     int maxa = 0;
     for (int r = 0; r < t.nown; r++) {
       const int a = lcnt[t.row0 - rb + r] >> 2;
-      if (a <= acap) {
+      const bool split = a > acap;
+      const bool join = !grp.empty() && !split && grp.back().count < 16 && grp.back().key <= acap &&
+                        firstcol[t.row0 - rb + r] >= 0 &&
+                        firstcol[t.row0 - rb + r] == firstcol[t.row0 - rb + r - 1];
+      if (!join) grp.push_back(Grp{(int32_t)tmp.size(), 0, 0});
+      if (!split) {
         tmp.push_back(VRow{r, 0, a});
+        grp.back().count++;
+        grp.back().key = std::max(grp.back().key, (int32_t)a);
         maxa = std::max(maxa, a);
       } else {
         const int parts = (a + acap - 1) / acap;
         for (int q = 0, k0 = 0; q < parts; q++) {
           const int ca = (a - k0 + (parts - q) - 1) / (parts - q); // even chunks
           tmp.push_back(VRow{r, k0, ca});
+          grp.back().count++;
+          grp.back().key = std::max(grp.back().key, (int32_t)(acap + 1)); // never joined
           maxa = std::max(maxa, ca);
           k0 += ca;
         }
       }
     }
+    // sort key of a split row's group: its longest chunk
+    for (auto &g : grp)
+      if (g.key > acap) {
+        int k = 0;
+        for (int q = 0; q < g.count; q++) k = std::max(k, (int)tmp[g.first + q].a);
+        g.key = k;
+      }
     std::vector<int32_t> cnt(maxa + 2, 0);
-    for (auto &v : tmp) cnt[maxa - v.a + 1]++;
+    for (auto &g : grp) cnt[maxa - g.key + 1] += g.count;
     for (int k = 0; k <= maxa; k++) cnt[k + 1] += cnt[k];
     vr.resize(tmp.size());
-    for (auto &v : tmp) vr[cnt[maxa - v.a]++] = v;
+    for (auto &g : grp) {
+      int32_t &pos = cnt[maxa - g.key];
+      for (int q = 0; q < g.count; q++) vr[pos++] = tmp[g.first + q];
+    }
+    for (size_t p0 = 0; p0 < vr.size(); p0 += kLanes) { // inside a slice: longest first
+      const size_t p1 = std::min(vr.size(), p0 + (size_t)kLanes);
+      std::stable_sort(vr.begin() + p0, vr.begin() + p1,
+                       [](const VRow &x, const VRow &y) { return x.a > y.a; });
+    }
   };
   std::vector<int64_t> tile_len(T, 0);
   {
@@ -538,6 +580,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     P.halo_col.assign((size_t)halo + 1, 0);
     P.slot_col.assign((size_t)nsl + 1, 0); // +1: the kernel's clamped dummy read
     P.slice_meta.assign((size_t)slices, SliceMeta{0u, 0u, 0ull});
+    P.leadlane.assign((size_t)slices * kLanes + kLanes, 0);
     P.rowinfo.assign((size_t)nvr + 1, 0);
     P.diag.assign((size_t)nvr + 1, V(0));
     P.nvrows = nvr;
@@ -545,12 +588,11 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 
   // ---- per tile: stream sizes, then fill ------------------------------------------
   // Multi-dof FEM matrices repeat themselves: the rows of one mesh node have
-  // (nearly) the same columns.  A lane whose whole packet-covered column
-  // sequence equals that of the lane before it (same packet count) does not
-  // store slots at all: it reads the slots of the last LEADER lane at or below
-  // it (same address -> one cache line serves the run).  One 64-bit leader
-  // mask per slice.  (Flan stand-in: 42 % of the slot stream disappears,
-  // ldoor: 61 %.)
+  // (nearly) the same columns.  A lane whose packet-covered column sequence is
+  // a PREFIX of the sequence of an earlier lane of its slice (earlier = at
+  // least as many packets) does not store slots at all: it reads the slots of
+  // that LEADER lane (same addresses -> the same cache lines serve the run).
+  // Per slice: a 64-bit leader mask, and one byte per lane naming its leader.
   std::vector<int64_t> tile_slen(T, 0);
   auto lower_cols = [&](int i, int k0, int cnt, std::vector<int32_t> &out) {
     out.clear();
@@ -564,7 +606,8 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 #pragma omp parallel num_threads(host_threads())
   {
     std::vector<VRow> vr;
-    std::vector<int32_t> prev, cur;
+    std::vector<int32_t> cur;
+    std::vector<std::vector<int32_t>> lseq(kLanes); // sequences of the slice's leaders
 #pragma omp for schedule(dynamic, 1)
     for (int ti = 0; ti < T; ti++) {
       Tile &t = P.tiles[ti];
@@ -580,25 +623,33 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
         sm.voff = (uint32_t)off;
         if (soff >= (1 << 25)) tile_slen[ti] = -1; // flagged below
         sm.soff_cnt0 = (uint32_t)soff;
-        prev.clear();
+        uint8_t *ll = P.leadlane.data() + (size_t)(t.slice_base + s) * kLanes;
         for (int p = p0; p < p1; p++) {
           const VRow &v = vr[p];
+          const int l = p - p0;
           off += (int64_t)v.a * 4;
           if (v.a >= 1) cnt0++;
-          bool leader = true;
+          int lead = l;
           if (v.a >= 1) {
             lower_cols(t.row0 + v.r, v.k0 * 4, v.a * 4, cur);
-            if (p > p0 && vr[p - 1].a == v.a && cur == prev) leader = false;
-            prev.swap(cur);
-          } else {
-            prev.clear();
+            // latest leaders first: siblings sit next to each other
+            for (int j = l - 1; j >= 0 && lead == l; j--)
+              if (((leaders >> j) & 1) && lseq[j].size() >= cur.size() && !lseq[j].empty() &&
+                  lseq[j][0] == cur[0] && std::equal(cur.begin(), cur.end(), lseq[j].begin()))
+                lead = j;
           }
-          if (leader) {
-            leaders |= 1ull << (p - p0);
+          ll[l] = (uint8_t)lead;
+          if (lead == l) {
+            leaders |= 1ull << l;
             soff += (int64_t)v.a * 4;
+            if (v.a >= 1) lseq[l].swap(cur);
+            else lseq[l].clear();
           }
         }
-        for (int l = p1 - p0; l < kLanes; l++) leaders |= 1ull << l; // unused lanes: own (empty) runs
+        for (int l = p1 - p0; l < kLanes; l++) { // unused lanes: own (empty) runs
+          leaders |= 1ull << l;
+          ll[l] = (uint8_t)l;
+        }
         sm.soff_cnt0 |= cnt0 << 25;
         sm.leaders = leaders;
       }
@@ -1183,15 +1234,21 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
       for (int g = 0; g < amax; g++) {
         int cnt = 0;
         while (cnt < kLanes && a[cnt] > g) cnt++;
-        int lead = -1;
+        // lane l reads the slots of its leader lane L = leadlane[l]; L's block is
+        // the (number of leaders below L)-th of the packet -- every leader below L
+        // has at least as many packets as L, hence is active whenever L is
+        const uint8_t *ll = P.leadlane.data() + (size_t)(t.slice_base + s) * kLanes;
+        int nlead = 0;
         for (int l = 0; l < cnt; l++) {
-          if ((sm.leaders >> l) & 1) lead++;
+          if ((sm.leaders >> l) & 1) nlead++;
+          const int L = ll[l];
+          const int rank = __builtin_popcountll(sm.leaders & ((1ull << L) - 1));
           for (int j = 0; j < kPacket; j++)
-            rows_out[r[l]].push_back({slot_col(ts[os + packet_slot_pos(lead, j)]),
+            rows_out[r[l]].push_back({slot_col(ts[os + packet_slot_pos(rank, j)]),
                                       tv[o + packet_val_pos<V>(l, j, cnt)]});
         }
         o += 4 * (int64_t)cnt;
-        os += 4 * (int64_t)(lead + 1);
+        os += 4 * (int64_t)nlead;
       }
     }
     const V *cv = P.cvals.data() + t.coo_off;
