@@ -752,7 +752,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     std::vector<uint32_t>().swap(P.rowinfo);
     std::vector<int32_t>().swap(P.fold_idx);
     std::vector<int32_t>().swap(P.send_idx);
-    return raise_lds_limit();
+    return 0;
   }
 
   // the instantiation of the tile kernel this handle launches
@@ -782,8 +782,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u);
     }
   }
-  const void *raised = nullptr; // kernel whose dynamic-LDS limit has been raised
-  int raise_lds_limit() { return 0; } // done lazily per instantiation in launch_tiles
+  const void *raised = nullptr; // instantiation whose dynamic-LDS limit has been raised (lazily, at launch)
 
   int launch_tiles(V *y, const V *x, hipStream_t st) {
     const void *k = tile_kernel();
