@@ -384,3 +384,41 @@ def test_build_shard_forms_agree_across_ranks():
         (used0, err0), (used1, err1) = res
         assert used0 == "none" and used1 == "all_to_all", res
         assert err0 <= 1e-12 and err1 <= 1e-12, res
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_shapes_parity(seed):
+    """the shapes of tests/test_plan_random.py through the kernels: banded, random, node
+    blocks, hub rows; random schedule options; whole matrix and mirrored shards"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import _lib
+    from oracle import oracle
+    from rand_matrices import random_matrix
+    torch = _torch()
+    rng = np.random.default_rng(5000 + seed)
+    kind = ["band", "random", "nodes", "hub"][seed % 4]
+    n, A = random_matrix(rng, int(rng.integers(300, 6000)), kind)
+    dtype = np.float64 if seed % 3 else np.float32
+    rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data.astype(dtype)
+    x = rng.uniform(-1, 1, n).astype(dtype)
+    opt = cfs.make_options(max_slots=int(rng.choice([0, 512, 2560])),
+                           block_threads=int(rng.choice([256, 512, 1024])),
+                           flags=int(rng.choice([0, 0, 8, 16])))
+    nranks = int(rng.choice([1, 1, 2, 4]))
+    rs = cfs.balanced_splits(n, rp, ci, nranks) if nranks > 1 else np.array([0, n], dtype=np.int32)
+    xd = torch.from_numpy(x).cuda()
+    y = np.zeros(n, dtype=dtype)
+    for r in range(nranks):
+        try:
+            M = cfs.SymMatrix(n, rp, ci, va, options=opt,
+                              row_splits=rs if nranks > 1 else None, rank=r)
+        except _lib.CfsHipError as e:
+            assert "dense row" in str(e), str(e)
+            return
+        yb = torch.full((int(rs[r + 1] - rs[r]),), float("nan"), dtype=xd.dtype, device="cuda")
+        M.spmv_phases(yb, xd, None, 7)
+        torch.cuda.synchronize()
+        y[rs[r]:rs[r + 1]] = yb.cpu().numpy()
+        M.close()
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
