@@ -546,12 +546,15 @@ __global__ void __launch_bounds__(256)
 }
 
 // general CSR, streaming form: a workgroup owns a block of consecutive rows whose
-// nonzeros fit its LDS product buffer; it streams colind/values fully coalesced
-// (4 independent loads per thread in flight), stores a_ij * x_j to LDS, then
-// every row is summed from LDS by CSR_RT lanes in stored order groups.  Rows
-// longer than the buffer get a block of their own and fall back to a
-// whole-workgroup strided sum.
-constexpr int kCsrNnz = 4096; // products per workgroup (32 KiB fp64)
+// nonzeros fit its LDS product buffer.  All of the block's colind / values loads
+// are issued at once (16 per thread, non-temporal: the matrix is read once per
+// SpMV), then all x gathers, then the products go to LDS -- three dependent round
+// trips per 4 096 nonzeros; the row pointers of the block are staged in LDS
+// alongside, so that the row sums (CSR_RT lanes per row, stored order) touch LDS
+// only.  Rows longer than the buffer get a block of their own and fall back to
+// a whole-workgroup strided sum.
+constexpr int kCsrNnz = 4096;  // products per workgroup (32 KiB fp64)
+constexpr int kCsrRows = 1024; // rows per block (row pointers in LDS)
 template <typename V>
 __global__ void __launch_bounds__(256)
     cfs_csr_stream_kernel(const int32_t *__restrict__ blk_row, int nblocks,
@@ -560,38 +563,45 @@ __global__ void __launch_bounds__(256)
                           const V *__restrict__ x, V *__restrict__ y) {
   __shared__ V prod[kCsrNnz];
   __shared__ V part[256];
+  __shared__ int32_t rps[kCsrRows + 1];
   const int tid = threadIdx.x;
+  constexpr int PER = kCsrNnz / 256;
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
     const int r0 = blk_row[b], r1 = blk_row[b + 1];
     const int p0 = rowptr[r0], p1 = rowptr[r1];
     const int n = p1 - p0;
     if (n <= kCsrNnz) {
-      for (int i = tid; i < n; i += 1024) { // 4 independent coalesced loads in flight
-        V v[4];
-        int c[4];
+      V v[PER];
+      int c[PER];
+      const int nr = r1 - r0;
+      int rpv[kCsrRows / 256 + 1];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int q = min(i + u * 256, n - 1);
-          v[u] = values[p0 + q];
-          c[u] = colind[p0 + q];
-        }
-        V xx[4];
+      for (int u = 0; u <= kCsrRows / 256; ++u) rpv[u] = rowptr[r0 + min(tid + u * 256, nr)];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) xx[u] = x[c[u]];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (i + u * 256 < n) prod[i + u * 256] = v[u] * xx[u];
+      for (int u = 0; u < PER; ++u) {
+        const int q = min(tid + u * 256, max(n, 1) - 1);
+        v[u] = __builtin_nontemporal_load(values + p0 + q);
+        c[u] = __builtin_nontemporal_load(colind + p0 + q);
       }
+#pragma unroll
+      for (int u = 0; u <= kCsrRows / 256; ++u)
+        if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
+      V xx[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) xx[u] = x[c[u]];
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+        if (tid + u * 256 < n) prod[tid + u * 256] = v[u] * xx[u];
       __syncthreads();
       // 4 lanes per row, rows strided over the workgroup
       const int sub = tid & 3;
-      for (int r = r0 + (tid >> 2); r < r1; r += 64) {
-        const int b0 = rowptr[r] - p0, e0 = rowptr[r + 1] - p0;
+      for (int r = tid >> 2; r < nr; r += 64) {
+        const int b0 = rps[r], e0 = rps[r + 1];
         V acc = V(0);
         for (int j = b0 + sub; j < e0; j += 4) acc += prod[j];
         acc += __shfl_down(acc, 2, 4);
         acc += __shfl_down(acc, 1, 4);
-        if (sub == 0) y[r] = acc;
+        if (sub == 0) y[r0 + r] = acc;
       }
       __syncthreads();
     } else { // one long row (r1 == r0 + 1 by construction)
@@ -620,7 +630,7 @@ struct DevBuf {
   }
   int upload(const void *src, size_t n) {
     bytes = n;
-    if (n == 0) n = 16;
+    n += 64; // padding: clamped / one-past-the-end reads of the kernels stay inside
     HIPCHK(hipMalloc(&p, n));
     if (bytes) HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
     return 0;
@@ -1445,7 +1455,7 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     int r = 0;
     while (r < nrows) {
       int e = r;
-      while (e < nrows && rowptr[e + 1] - rowptr[r] <= kCsrNnz && e - r < 4096) e++;
+      while (e < nrows && rowptr[e + 1] - rowptr[r] <= kCsrNnz && e - r < kCsrRows) e++;
       if (e == r) e = r + 1;
       blk.push_back(e);
       r = e;
