@@ -1083,14 +1083,63 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     delete m;
     return rc;
   }
+  // ---- window shape (Tuning::Aggressive; CFS_HIP_FLAG_NO_CALIBRATE skips it) -------
+  // Default: 512 threads, 4 992 slots, two workgroups per CU.  A matrix that is
+  // scheduled in clustered order (compact 3-D tiles) can be faster with ONE
+  // workgroup of 1 024 threads and a window twice the size per CU -- half as many,
+  // larger tiles, a quarter fewer halo slots, a shorter fold (Flan stand-in fp64:
+  // 0.122 -> 0.116 ms per SpMV; fp32, ldoor, pwtk, Queen: no gain or a loss).
+  // Both schedules are built and timed; the faster one is kept.
+  const bool tuning = !(opt && (opt->flags & CFS_HIP_FLAG_NO_CALIBRATE)) &&
+                      m->P.nnz_low >= (int64_t)2000000;
+  if (tuning && !m->P.perm.empty() && po.block_threads == 0 && po.max_slots == 0) {
+    DevBuf xb, yb;
+    if ((rc = xb.alloc((size_t)n * sizeof(V))) || (rc = yb.alloc((size_t)m->rows() * sizeof(V)))) {
+      delete m;
+      return rc;
+    }
+    (void)hipMemset(xb.p, 0x3f, xb.bytes); // small positive values
+    auto time_spmv = [&](SymMatrix<V> *h, float *ms) -> int {
+      hipEvent_t a, b;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+      int r2 = 0;
+      for (int it = 0; it < 3 && !r2; it++) r2 = h->spmv_local(yb.p, xb.p, nullptr, (hipStream_t)0, 3);
+      (void)hipEventRecord(a, (hipStream_t)0);
+      for (int it = 0; it < 10 && !r2; it++) r2 = h->spmv_local(yb.p, xb.p, nullptr, (hipStream_t)0, 3);
+      (void)hipEventRecord(b, (hipStream_t)0);
+      if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(ms, a, b) != hipSuccess) r2 = -1;
+      (void)hipEventDestroy(a);
+      (void)hipEventDestroy(b);
+      return r2;
+    };
+    cfs_plan::Options po2 = po;
+    po2.block_threads = 1024;
+    po2.max_slots = 2 * cfs_plan::kDefaultSlots;
+    auto *alt = new SymMatrix<V>();
+    alt->value_bytes = (int)sizeof(V);
+    float t_def = 0, t_alt = 0;
+    const bool ok = query_residency<V>(po2) == 0 &&
+                    cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
+                                            nranks > 1 ? row_splits : nullptr, po2, alt->P) &&
+                    alt->upload() == 0 && time_spmv(m, &t_def) == 0 && time_spmv(alt, &t_alt) == 0;
+    if (getenv("CFS_PLAN_VERBOSE"))
+      fprintf(stderr, "[cfs_hip] window shape: 512 x 2 per CU %.1f us, 1024 x 1 per CU %.1f us%s\n",
+              t_def * 100.0, t_alt * 100.0, ok ? "" : " (alternative not built)");
+    if (ok && t_alt < 0.99f * t_def) {
+      delete m;
+      m = alt;
+      po = po2;
+    } else {
+      delete alt;
+    }
+  }
   // ---- XCD calibration (Tuning::Aggressive; CFS_HIP_FLAG_NO_CALIBRATE skips it) ----
   // The eight XCDs do not stream at the same rate (measured: the groups dealt
   // to XCD labels 4-6 finish ~7 % later than those of label 7, box after box)
   // and the launch is as long as its slowest XCD.  Measure the mean finish time
   // per XCD label with the timeline build of the kernel and re-cut the rows with
   // per-XCD shares; keep the new schedule only if its launches end earlier.
-  if (!(opt && (opt->flags & CFS_HIP_FLAG_NO_CALIBRATE)) && m->P.ngroups >= 64 &&
-      m->P.nnz_low >= (int64_t)2000000) {
+  if (tuning && m->P.ngroups >= 64) {
     const int G = m->P.ngroups, nper = G >> 3;
     DevBuf xb, yb;
     if ((rc = xb.alloc((size_t)n * sizeof(V))) || (rc = yb.alloc((size_t)m->rows() * sizeof(V)))) {
