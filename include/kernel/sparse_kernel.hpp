@@ -1,7 +1,15 @@
-// kernel/sparse_kernel.hpp -- the SpDMV functor (reference:
-// include/kernel/sparse_kernel.hpp:17-27, sparse_kernel.tpp:9-27): the
-// constructor tunes the matrix, the call operator checks the dimensions and
-// multiplies.
+// kernel/sparse_kernel.hpp -- SpDMV, the sparse-matrix times dense-vector functor.
+//
+// Mirrors the reference's operator (include/kernel/sparse_kernel.hpp:17-27,
+// sparse_kernel.tpp:9-27) so that callers compile unchanged:
+//
+//     SpDMV<int, double> spmv(A);        // tunes A: builds the MI355X tile schedule
+//     spmv(y, M, x, N);                  // y <- A x ; M == A->nrows(), N == A->ncols()
+//
+// x and y may be host pointers (staged through HBM on every call -- the
+// unmodified-caller path) or Platform::gpu pointers from internal_alloc (resident:
+// the call is enqueued; cfs::util::runtime::synchronize() or internal_copy wait).
+// y is fully overwritten and needs no zeroing.  The functor does not own A.
 #ifndef CFS_SPARSE_KERNEL_HPP
 #define CFS_SPARSE_KERNEL_HPP
 
@@ -18,14 +26,22 @@ namespace kernel {
 namespace sparse {
 
 template <typename IndexType, typename ValueType> struct SpDMV {
-public:
+  typedef SparseMatrix<IndexType, ValueType> matrix_type;
+
+  // tune() happens here, as in the reference (sparse_kernel.tpp:9-13); what the
+  // Tuning levels mean on the GPU is described at CSRMatrix::tune (src/csr.cpp)
+  SpDMV(matrix_type *A, Tuning t = Tuning::Aggressive);
   SpDMV() = delete;
-  SpDMV(SparseMatrix<IndexType, ValueType> *A, Tuning t = Tuning::Aggressive);
+
+  // dimensions are asserted, then forwarded to A->dense_vector_multiply(y, x)
   void operator()(ValueType *__restrict y, const int M, const ValueType *__restrict x,
                   const int N);
 
+  // the operand this functor was built for (not in the reference; read-only helper)
+  const matrix_type *matrix() const { return A_; }
+
 private:
-  SparseMatrix<IndexType, ValueType> *A_;
+  matrix_type *A_;
 };
 
 } // namespace sparse

@@ -1,6 +1,7 @@
-// utils/platform.hpp -- enumerations and the result-comparison helper of the
-// cfs-spmv operator surface (mirrors the reference's include/utils/platform.hpp:20-37:
-// same names, same enumerator values; `gpu` is appended so that cpu stays 0).
+// utils/platform.hpp -- the enumerations of the operator surface and the
+// comparison helper of the self-check.  Names and enumerator values are the
+// reference's (include/utils/platform.hpp:20-37); Platform::gpu is appended so
+// that cpu keeps the value 0.
 #ifndef CFS_PLATFORM_HPP
 #define CFS_PLATFORM_HPP
 
@@ -13,17 +14,26 @@ namespace util {
 
 using namespace std;
 
-// Platform::cpu is kept for source compatibility only: this build runs the hot
-// path on the GPU and refuses (loudly) a matrix explicitly created for cpu.
+// where a matrix / a vector lives.  cpu: host memory (vectors) -- a MATRIX created
+// for cpu is refused, this build has no CPU kernels.  gpu: HBM of the bound MI355X.
 enum class Platform { cpu, gpu };
+
+// the one kernel of the library: sparse matrix times dense vector
 enum class Kernel { SpDMV };
+
+// None: one schedule build.  Aggressive (default): also the measured steps of
+// tune() -- window shape and per-XCD work shares (csr.cpp, cfs_hip.h).
 enum class Tuning { None, Aggressive };
+
+// storage asked for at create(): csr = every stored entry; sss = symmetric, lower
+// triangle + diagonal; hyb = treated as sss here; none = unset
 enum class Format { none, csr, sss, hyb };
 
+// ceil(a / b) for positive ints (partition sizes)
 inline int iceildiv(const int a, const int b) { return (a + b - 1) / b; }
 
-// The reference's pass criterion (Knuth 4.2.2): |x - y| <= eps * |x| with
-// eps = 1e-4 for float and 1e-8 for double.
+// Pass criterion of the self-check, the reference's (Knuth 4.2.2, relative to the
+// first argument): eps = 1e-4 in single, 1e-8 in double precision.
 inline bool isEqual(float x, float y) { return fabsf(x - y) <= 1e-4f * fabsf(x); }
 inline bool isEqual(double x, double y) { return fabs(x - y) <= 1e-8 * fabs(x); }
 

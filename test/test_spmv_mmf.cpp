@@ -1,71 +1,95 @@
-// test_spmv_mmf -- self-check of the MI355X build, same protocol as the
-// reference's only test (test/test_spmv_mmf.cpp:31-120): multiply twice with the
-// requested format on an un-zeroed y, multiply once with plain CSR
-// (Tuning::None), compare element-wise with isEqual, print PASSED!/FAILED!.
-// Host pointers are used on purpose: this is the unmodified-caller path.
+// test_spmv_mmf -- self-check of the MI355X build.
+//
 //     test_spmv_mmf <mmf_file> <format>(0: CSR, 1: CFS-SSS, 2: CFH-SSS)
+//
+// Protocol of the reference's only test (test/test_spmv_mmf.cpp:31-120): the
+// matrix in the requested format multiplies a random vector twice into a y that
+// was never zeroed; the same file as plain CSR (Tuning::None) multiplies it once;
+// the two results must agree element-wise under isEqual.  Prints PASSED! /
+// FAILED!.  Host vectors on purpose: this is what an unmodified caller does.
+// CFS_SEED fixes the random vector (the reference draws from random_device).
 #include <cstdlib>
 #include <iostream>
 #include <random>
+#include <string>
 
 #include "cfs.hpp"
 
-using namespace std;
-using namespace cfs::util;
-using namespace cfs::util::memory;
-using namespace cfs::matrix::sparse;
-using namespace cfs::kernel::sparse;
+namespace {
 
 typedef int INDEX;
 typedef double VALUE;
+typedef cfs::matrix::sparse::SparseMatrix<INDEX, VALUE> Matrix;
+typedef cfs::kernel::sparse::SpDMV<INDEX, VALUE> Multiply;
+
+// a host vector from the library's allocator, released on scope exit
+struct HostVector {
+  VALUE *p;
+  explicit HostVector(int n)
+      : p((VALUE *)cfs::util::memory::internal_alloc((size_t)n * sizeof(VALUE))) {}
+  ~HostVector() { cfs::util::memory::internal_free(p); }
+  VALUE &operator[](int i) { return p[i]; }
+};
+
+bool parse_format(const char *arg, cfs::util::Format *out) {
+  const int k = atoi(arg);
+  if (k == 0) *out = cfs::util::Format::csr;
+  else if (k == 1) *out = cfs::util::Format::sss;
+  else if (k == 2) *out = cfs::util::Format::hyb;
+  else return false;
+  return true;
+}
+
+void fill_uniform(HostVector &v, int n, double lo, double hi) {
+  const char *seed = getenv("CFS_SEED");
+  std::mt19937 gen(seed ? (unsigned)atoi(seed) : std::random_device()());
+  std::uniform_real_distribution<> draw(lo, hi);
+  for (int i = 0; i < n; i++) v[i] = draw(gen);
+}
+
+// index of the first element the two vectors disagree on, or -1
+int first_mismatch(HostVector &a, HostVector &b, int n) {
+  for (int i = 0; i < n; i++)
+    if (!cfs::util::isEqual(a[i], b[i])) return i;
+  return -1;
+}
+
+} // namespace
 
 int main(int argc, char **argv) {
+  cfs::util::Format fmt;
   if (argc < 3) {
-    cerr << "Error in number of arguments!" << endl;
-    cout << "Usage: " << argv[0] << " <mmf_file> <format>(0: CSR, 1: CFS-SSS, 2: CFH-SSS)"
-         << endl;
+    std::cerr << "Error in number of arguments!" << std::endl;
+    std::cout << "Usage: " << argv[0]
+              << " <mmf_file> <format>(0: CSR, 1: CFS-SSS, 2: CFH-SSS)" << std::endl;
     return 1;
   }
-  const string mmf_file(argv[1]);
-  const int fmt = atoi(argv[2]);
-  if (fmt < 0 || fmt > 2) {
-    cerr << "Error in arguments!" << endl;
+  if (!parse_format(argv[2], &fmt)) {
+    std::cerr << "Error in arguments!" << std::endl;
     return 1;
   }
-  static const Format formats[] = {Format::csr, Format::sss, Format::hyb};
-  SparseMatrix<INDEX, VALUE> *A = SparseMatrix<INDEX, VALUE>::create(mmf_file, formats[fmt]);
-  const int M = A->nrows(), N = A->ncols();
+  const std::string file(argv[1]);
 
-  VALUE *x = (VALUE *)internal_alloc((size_t)N * sizeof(VALUE));
-  VALUE *y = (VALUE *)internal_alloc((size_t)M * sizeof(VALUE));
-  const char *seed_env = getenv("CFS_SEED");
-  mt19937 gen(seed_env ? (unsigned)atoi(seed_env) : random_device()());
-  uniform_real_distribution<> dis_val(10.01, 20.42);
-  for (int i = 0; i < N; i++) x[i] = dis_val(gen);
-  for (int i = 0; i < M; i++) y[i] = -12345.678; // never zeroed by the reference: poison it
+  Matrix *A = Matrix::create(file, fmt);
+  const int rows = A->nrows(), cols = A->ncols();
+  HostVector x(cols), y(rows), y_csr(rows);
+  fill_uniform(x, cols, 10.01, 20.42);
+  for (int i = 0; i < rows; i++) y[i] = -12345.678; // the reference never zeroes y: poison it
 
-  SpDMV<INDEX, VALUE> fn(A, Tuning::Aggressive);
-  for (int i = 0; i < 2; ++i) fn(y, M, x, N);
+  Multiply multiply(A, cfs::util::Tuning::Aggressive);
+  multiply(y.p, rows, x.p, cols);
+  multiply(y.p, rows, x.p, cols); // twice: the second call must not see the first
 
-  SparseMatrix<INDEX, VALUE> *A_test = SparseMatrix<INDEX, VALUE>::create(mmf_file, Format::csr);
-  SpDMV<INDEX, VALUE> test(A_test, Tuning::None);
-  VALUE *y_test = (VALUE *)internal_alloc((size_t)M * sizeof(VALUE));
-  test(y_test, M, x, N);
+  Matrix *G = Matrix::create(file, cfs::util::Format::csr);
+  Multiply ground_truth(G, cfs::util::Tuning::None);
+  ground_truth(y_csr.p, rows, x.p, cols);
 
-  bool passed = true;
-  for (INDEX i = 0; i < M; i++) {
-    if (!isEqual(y[i], y_test[i])) {
-      cout << "element " << i << " differs: " << y[i] << " vs " << y_test[i] << endl;
-      passed = false;
-      break;
-    }
-  }
-  cout << (passed ? "PASSED!" : "FAILED!") << endl;
+  const int bad = first_mismatch(y, y_csr, rows);
+  if (bad >= 0)
+    std::cout << "element " << bad << " differs: " << y[bad] << " vs " << y_csr[bad] << std::endl;
+  std::cout << (bad < 0 ? "PASSED!" : "FAILED!") << std::endl;
 
   delete A;
-  delete A_test;
-  internal_free(x);
-  internal_free(y);
-  internal_free(y_test);
-  return passed ? 0 : 2;
+  delete G;
+  return bad < 0 ? 0 : 2;
 }
