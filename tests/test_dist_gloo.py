@@ -177,3 +177,84 @@ def test_sharded_cg_gloo():
         assert not isinstance(err, str), f"rank {rank} failed: {err}"
         assert err <= 1e-9 and rr <= 1e-10 and 0 < it < 400, (rank, err, it, rr)
     assert res[0][2] == res[1][2]  # same iteration count on every rank
+
+
+class HostMirroredDouble:
+    """host stand-in of a MIRRORED shard: every entry that touches a row of the block is
+    stored by this rank, so its block of y needs nothing from anyone"""
+
+    def __init__(self, n, rp, ci, va, nranks, rank, rs):
+        import scipy.sparse as sp
+        self.row_begin, self.row_end = int(rs[rank]), int(rs[rank + 1])
+        self.B = sp.csr_matrix((va, ci, rp), shape=(n, n))[self.row_begin:self.row_end, :]
+        self.nranks = nranks
+
+    def send_counts(self):
+        return np.zeros(self.nranks, dtype=np.int32)
+
+    def send_rows(self):
+        return np.zeros(0, dtype=np.int32)
+
+    def spmv_phases(self, y_block, x, send, phases):
+        if phases & 1:
+            y_block.numpy()[:] = self.B @ x.numpy()
+
+
+def _mirror_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch
+        import torch.distributed as dist
+        import scipy.sparse as sp
+        import scipy.sparse.linalg as spl
+        import cfs_spmv_amd as cfs
+        from cfs_spmv_amd import synth
+        from cfs_spmv_amd.dist import ShardedSym
+        from cfs_spmv_amd.solver import cg_sharded
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        n, rp, ci, va, _ = synth.generate("pwtk", 0.02)
+        rs = cfs.balanced_splits(n, rp, ci, world)
+        # the real schedule of this rank's mirrored shard: nothing to send
+        rep = cfs.plan_check(n, rp, ci, va, world, rank, rs)
+        assert rep["mismatches"] == 0 and rep["remote_vals"] == 0
+        be = HostMirroredDouble(n, rp, ci, va, world, rank, rs)
+        sh = ShardedSym(be, world, rank, np.float64, torch.device("cpu"), exchange="none")
+        x = synth.make_x(n)
+        yb = torch.full((be.row_end - be.row_begin,), 7.0, dtype=torch.float64)
+        sh.spmv(yb, torch.from_numpy(x.copy()))
+        A = sp.csr_matrix((va, ci, rp), shape=(n, n))
+        err = float(np.max(np.abs(yb.numpy() - (A @ x)[be.row_begin:be.row_end])))
+        b = synth.make_x(n, 7)
+        u, it, res = cg_sharded(sh, rs, torch.from_numpy(b[be.row_begin:be.row_end].copy()),
+                                tol=1e-11, maxiter=400)
+        u_ref = spl.spsolve(sp.csc_matrix(A), b)
+        cg_err = float(np.max(np.abs(u.numpy() - u_ref[be.row_begin:be.row_end])) / np.max(np.abs(u_ref)))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, err, cg_err, res))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, f"{e}\n{traceback.format_exc()}", 0.0, 0.0))
+
+
+def test_mirrored_form_needs_no_collective_gloo():
+    """exchange='none' (the default of build_shard): SpMV without any collective; the
+    solver loop on top only all-gathers its vectors"""
+    import torch.multiprocessing as mp
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mirror_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, err, cg_err, rr in res:
+        assert not isinstance(err, str), f"rank {rank} failed: {err}"
+        assert err <= 1e-10 and cg_err <= 1e-9 and rr <= 1e-10, (rank, err, cg_err, rr)
