@@ -391,9 +391,9 @@ int cfs_mmf_load_csr_f64(const char *path, int *nrows, int *ncols, long *nnz, in
   *rowptr = (int *)malloc(sizeof(int) * a.rowptr.size());
   *colind = (int *)malloc(sizeof(int) * (a.colind.size() + 1));
   *values = (double *)malloc(sizeof(double) * (a.values.size() + 1));
-  memcpy(*rowptr, a.rowptr.data(), sizeof(int) * a.rowptr.size());
-  memcpy(*colind, a.colind.data(), sizeof(int) * a.colind.size());
-  memcpy(*values, a.values.data(), sizeof(double) * a.values.size());
+  if (!a.rowptr.empty()) memcpy(*rowptr, a.rowptr.data(), sizeof(int) * a.rowptr.size());
+  if (!a.colind.empty()) memcpy(*colind, a.colind.data(), sizeof(int) * a.colind.size());
+  if (!a.values.empty()) memcpy(*values, a.values.data(), sizeof(double) * a.values.size());
   return 0;
 }
 void cfs_mmf_free(void *p) { free(p); }

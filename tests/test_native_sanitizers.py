@@ -21,3 +21,39 @@ def test_schedule_builder_is_clean_under_asan_ubsan(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="4", ASAN_OPTIONS="detect_leaks=0")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout + r.stderr)[-4000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="g++ not available")
+def test_parallel_reader_is_clean_under_asan_ubsan(tmp_path):
+    """golden fixtures plus malformed files: truncated lines, missing trailing newline,
+    indices out of range, a size line that promises more than the body holds, junk"""
+    exe = str(tmp_path / "asan_reader")
+    srcs = [os.path.join(ROOT, "src", "mmf.cpp"), os.path.join(ROOT, "tests", "native", "asan_reader.cpp")]
+    # get_host_threads() is the only thing the reader needs from runtime.cpp; give the
+    # harness its own so that it links without the HIP library
+    shim = tmp_path / "threads.cpp"
+    shim.write_text("namespace cfs { namespace util { namespace runtime { int get_host_threads() { return 4; } } } }\n")
+    cmd = ["g++", "-std=c++11", "-O1", "-g", "-fopenmp", "-fsanitize=address,undefined",
+           "-fno-sanitize-recover=undefined", "-I", os.path.join(ROOT, "include")] + srcs + \
+          [str(shim), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    gold = os.path.join(ROOT, "tests", "golden")
+    files = sorted(os.path.join(gold, f) for f in os.listdir(gold) if f.endswith(".mtx"))
+    bad = {
+        "trunc.mtx": "%%MatrixMarket matrix coordinate real symmetric\n5 5 4\n1 1 1.0\n2 1\n3",
+        "nonl.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 1.0\n3 2 2.5",
+        "range.mtx": "%%MatrixMarket matrix coordinate real general\n3 3 2\n7 1 1.0\n0 9 2.0\n",
+        "short.mtx": "%%MatrixMarket matrix coordinate real symmetric\n4 4 100\n2 1 1.0\n",
+        "junk.mtx": "hello world\n\n\n1 2 three\n" + "x" * 5000,
+        "empty.mtx": "",
+        "sizeonly.mtx": "%%MatrixMarket matrix coordinate real general\n0 0 0\n",
+        "neg.mtx": "%%MatrixMarket matrix coordinate real general\n-3 3 2\n1 1 1.0\n",
+        "huge.mtx": "%%MatrixMarket matrix coordinate real general\n2147483647 2147483647 3\n1 1 1.0\n",
+    }
+    for name, text in bad.items():
+        (tmp_path / name).write_text(text)
+        files.append(str(tmp_path / name))
+    env = dict(os.environ, OMP_NUM_THREADS="4", ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe] + files, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout + r.stderr)[-4000:]
