@@ -1118,10 +1118,16 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     auto *alt = new SymMatrix<V>();
     alt->value_bytes = (int)sizeof(V);
     float t_def = 0, t_alt = 0;
-    const bool ok = query_residency<V>(po2) == 0 &&
-                    cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                                            nranks > 1 ? row_splits : nullptr, po2, alt->P) &&
-                    alt->upload() == 0 && time_spmv(m, &t_def) == 0 && time_spmv(alt, &t_alt) == 0;
+    bool ok = query_residency<V>(po2) == 0 &&
+              cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
+                                      nranks > 1 ? row_splits : nullptr, po2, alt->P) &&
+              alt->upload() == 0;
+    for (int round = 0; ok && round < 3; round++) { // interleaved, best of three each
+      float a = 0, b = 0;
+      ok = time_spmv(m, &a) == 0 && time_spmv(alt, &b) == 0;
+      t_def = round == 0 ? a : std::min(t_def, a);
+      t_alt = round == 0 ? b : std::min(t_alt, b);
+    }
     if (getenv("CFS_PLAN_VERBOSE"))
       fprintf(stderr, "[cfs_hip] window shape: 512 x 2 per CU %.1f us, 1024 x 1 per CU %.1f us%s\n",
               t_def * 100.0, t_alt * 100.0, ok ? "" : " (alternative not built)");
