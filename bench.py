@@ -150,7 +150,23 @@ def main():
 
     np_dt = np.float64 if args.dtype == "f64" else np.float32
     t_dt = torch.float64 if args.dtype == "f64" else torch.float32
-    n, rp, ci, va, nnz_low = synth.generate(args.matrix, args.scale)
+    # the real SuiteSparse file when the user provides it ($CFS_MTX_DIR/<name>.mtx,
+    # through the C++ surface's reader); offline, SURVEY 8d's stand-in generator
+    from cfs_spmv_amd import mmf
+    real = mmf.find_real_matrix(args.matrix) if args.scale == 1.0 else None
+    if real:
+        A0 = mmf.load_mtx(real)
+        if not A0["symmetric"] or A0["nrows"] != A0["ncols"]:
+            raise SystemExit(f"{real}: not a symmetric matrix")
+        n, rp, ci, va = A0["nrows"], A0["rowptr"], A0["colind"], A0["values"]
+        rows_of = np.repeat(np.arange(n, dtype=np.int32), np.diff(rp))
+        nnz_low = int(np.count_nonzero(ci < rows_of))
+        del rows_of, A0
+        data_kind, source = "file", f"{os.path.basename(real)} (SuiteSparse file)"
+    else:
+        n, rp, ci, va, nnz_low = synth.generate(args.matrix, args.scale)
+        data_kind = "synthetic"
+        source = f"{args.matrix}-like synthetic (SURVEY 8d generator), scale {args.scale}"
     va = va.astype(np_dt, copy=False)
     nnz_full = int(rp[-1])
     x_host = synth.make_x(n, 42, np_dt)
@@ -283,10 +299,9 @@ def main():
             "unit": "GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
+            "dtype": args.dtype, "data": data_kind,
             "config": {
-                "workload": f"{args.matrix}-like synthetic (SURVEY 8d generator), "
-                            f"scale {args.scale}: n={n}, nnz_full={nnz_full}, "
+                "workload": f"{source}: n={n}, nnz_full={nnz_full}, "
                             f"nnz_low={nnz_low}, symmetric SSS SpMV y=Ax",
                 "format": "sss", "sharding": f"1d-row-blocks x{N}",
                 "exchange": (None if sh is None else

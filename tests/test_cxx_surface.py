@@ -9,6 +9,7 @@ import glob
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -169,3 +170,20 @@ def test_binary_cache_roundtrip(tmp_path, monkeypatch):
         f.write("% trailing comment\n")
     d = cxx_load(p)
     assert d["values"][-1] == a["values"][-1]
+
+
+@pytest.mark.gpu
+def test_bench_takes_a_real_file_from_cfs_mtx_dir(tmp_path):
+    """the stand-ins are only used when $CFS_MTX_DIR/<name>.mtx is absent"""
+    import json
+    from cfs_spmv_amd import synth
+    n, rp, ci, va, low = synth.generate("pwtk", 0.05)
+    synth.write_mtx(str(tmp_path / "pwtk.mtx"), n, rp, ci, va)
+    env = dict(os.environ, CFS_MTX_DIR=str(tmp_path))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--matrix", "pwtk",
+                        "--steps", "10", "--warmup", "3", "--no-cpu-baseline"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["data"] == "file" and "pwtk.mtx" in d["config"]["workload"]
+    assert f"n={n}," in d["config"]["workload"] and f"nnz_low={low}," in d["config"]["workload"]
