@@ -53,7 +53,61 @@ inline bool tok_is(const Tokens &t, int i, const char *s) {
 }
 // atoi on a token (the token is followed by a blank or '\n', so strtol stops)
 inline long tok_long(const Tokens &t, int i) { return strtol(t.b[i], nullptr, 10); }
-inline double tok_double(const Tokens &t, int i) { return strtod(t.b[i], nullptr); }
+// atof on a token, bit-exact with strtod: Clinger's fast path -- at most 15
+// significant digits (mantissa < 2^53) and a decimal exponent within +-22 are ONE
+// correctly rounded multiplication / division of two exact doubles -- covers what
+// SuiteSparse files usually hold; everything else (17-digit values, huge or tiny
+// exponents, inf / nan / hex) goes to strtod itself.
+inline double tok_double(const Tokens &t, int i) {
+  static const double p10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,
+                                 1e8,  1e9,  1e10, 1e11, 1e12, 1e13, 1e14, 1e15,
+                                 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+  const char *b = t.b[i], *e = t.e[i], *q = b;
+  bool neg = false;
+  if (q < e && (*q == '-' || *q == '+')) neg = *q++ == '-';
+  unsigned long long m = 0;
+  int digits = 0, exp10 = 0;
+  bool any = false, ok = true;
+  while (q < e && *q >= '0' && *q <= '9') {
+    if (m || *q != '0') digits++;
+    if (digits <= 15) m = m * 10 + (unsigned)(*q - '0');
+    else ok = false;
+    any = true;
+    q++;
+  }
+  if (q < e && *q == '.') {
+    q++;
+    while (q < e && *q >= '0' && *q <= '9') {
+      if (m || *q != '0') digits++;
+      if (digits <= 15) {
+        m = m * 10 + (unsigned)(*q - '0');
+        exp10--;
+      } else {
+        ok = false;
+      }
+      any = true;
+      q++;
+    }
+  }
+  if (any && q < e && (*q == 'e' || *q == 'E')) {
+    const char *r = q + 1;
+    bool eneg = false;
+    if (r < e && (*r == '-' || *r == '+')) eneg = *r++ == '-';
+    int ev = 0, nd = 0;
+    while (r < e && *r >= '0' && *r <= '9' && nd < 5) {
+      ev = ev * 10 + (*r - '0');
+      r++;
+      nd++;
+    }
+    if (nd == 0 || (r < e && *r >= '0' && *r <= '9')) ok = false;
+    exp10 += eneg ? -ev : ev;
+    q = r;
+  }
+  if (!any || !ok || q != e || exp10 < -22 || exp10 > 22) return strtod(b, nullptr);
+  double v = (double)m; // exact: m < 10^15 < 2^53
+  v = exp10 < 0 ? v / p10[-exp10] : v * p10[exp10];
+  return neg ? -v : v;
+}
 
 struct Elem {
   int row, col; // zero-based here
@@ -238,6 +292,15 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
     return false;
   }
 
+  // CFS_MMF_VERBOSE=1 prints where the reader spends its time
+  const bool verbose = getenv("CFS_MMF_VERBOSE") != nullptr;
+  double t_last = omp_get_wtime();
+  auto lap = [&](const char *what) {
+    if (!verbose) return;
+    const double now = omp_get_wtime();
+    fprintf(stderr, "[cfs_mmf] %-28s %8.3f s\n", what, now - t_last);
+    t_last = now;
+  };
   // ---- entries: cut the body at line boundaries, parse in parallel --------------
   const char *body = p;
   const int nth = std::max(1, cfs::util::runtime::get_host_threads());
@@ -276,6 +339,7 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
       v.push_back(el);
     }
   }
+  lap("parse (parallel)");
   long read = 0;
   for (int i = 0; i < nth; i++) {
     if (bad[i]) {
@@ -312,6 +376,7 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
     return false;
   }
   for (long r = 0; r < nrows; r++) rowcnt[r + 1] += rowcnt[r];
+  lap("count rows");
   const long nnz = rowcnt[nrows];
   if (nnz > 0x7fffffffL) {
     error = "more than 2^31-1 nonzeros: int indices are API (src/csr.cpp)";
@@ -335,6 +400,7 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
       }
     for (auto &v : part) std::vector<Elem>().swap(v);
   }
+  lap("bucket by row");
   out.nrows = (IndexType)nrows;
   out.ncols = (IndexType)ncols;
   out.nnz = nnz;
@@ -355,6 +421,7 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
     }
   }
   for (long r = 0; r <= nrows; r++) out.rowptr[r] = (IndexType)rowcnt[r];
+  lap("sort rows + emit");
   // the reference asserts that the last row is non-empty (csr_matrix.tpp:104)
   if (nrows > 0 && rowcnt[nrows] == rowcnt[nrows - 1] && nnz > 0) {
     // accepted here: trailing empty rows simply repeat rowptr

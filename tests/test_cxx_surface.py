@@ -187,3 +187,31 @@ def test_bench_takes_a_real_file_from_cfs_mtx_dir(tmp_path):
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["data"] == "file" and "pwtk.mtx" in d["config"]["workload"]
     assert f"n={n}," in d["config"]["workload"] and f"nnz_low={low}," in d["config"]["workload"]
+
+
+def test_value_parser_is_bit_exact_with_strtod(tmp_path):
+    """the reader's fast path for short decimals (Clinger) and its strtod fall-back give
+    the correctly rounded double for every spelling -- what the reference's atof returns"""
+    import random
+    import struct
+    rnd = random.Random(7)
+    strs = ["0", "-0", "0.0", "1", "-1", "1e22", "1e23", "1e-22", "1e-23", "123456789012345",
+            "1234567890123456", "0.000001", "5e-324", "1.7976931348623157e308", "+3.5", "1.",
+            "-.5", "00012.5000", "9007199254740993", "0.1e1", "1E+2", "4.9406564584124654e-324",
+            "2.2250738585072014e-308", "1e400", "-1e-400", "0.3", "0.1", "123456.789e-3"]
+    fmts = ["%.17g", "%.15g", "%.6e", "%.3f", "%g", "%.12E", "%.16g", "%.1f"]
+    for _ in range(20000):
+        v = rnd.choice([rnd.uniform(-1, 1), rnd.uniform(-1e6, 1e6),
+                        rnd.gauss(0, 1) * 10 ** rnd.randint(-30, 30),
+                        float(rnd.randint(-10 ** 9, 10 ** 9))])
+        strs.append(rnd.choice(fmts) % v)
+    p = tmp_path / "values.mtx"
+    with open(p, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n%d 1 %d\n" % (len(strs), len(strs)))
+        for i, sv in enumerate(strs):
+            f.write("%d 1 %s\n" % (i + 1, sv))
+    got = cxx_load(str(p))["values"]
+    exp = np.array([float(sv) for sv in strs])  # Python's float() is correctly rounded
+    bad = [(strs[i], exp[i], got[i]) for i in range(len(strs))
+           if struct.pack("d", exp[i]) != struct.pack("d", got[i])]
+    assert not bad, bad[:5]
