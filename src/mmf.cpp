@@ -355,20 +355,31 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
   // the reference reads exactly `declared` entries and ignores the rest
   long keep = declared;
   // ---- expand, bucket by row (counting sort), order each row by column ----------
+  // Entries beyond the declared count are ignored: trim the parts first, so that
+  // both passes below can run one thread per part.  `base[i]` = entries of the
+  // parts before i (the file order of an entry = base + its index in its part).
+  std::vector<long> base(nth + 1, 0);
+  for (int i = 0; i < nth; i++) {
+    const long room = keep - base[i];
+    if ((long)part[i].size() > room) part[i].resize((size_t)std::max(0L, room));
+    base[i + 1] = base[i] + (long)part[i].size();
+  }
   std::vector<long> rowcnt((size_t)nrows + 1, 0);
-  long seen = 0;
   bool range_error = false;
-  for (int i = 0; i < nth && seen < keep; i++)
-    for (size_t k = 0; k < part[i].size() && seen < keep; k++, seen++) {
+#pragma omp parallel for schedule(static, 1) num_threads(nth)
+  for (int i = 0; i < nth; i++)
+    for (size_t k = 0; k < part[i].size(); k++) {
       const Elem &el = part[i][k];
-      if (el.row < 0 || el.row >= nrows || el.col < 0 || el.col >= ncols) {
+      if (el.row < 0 || el.row >= nrows || el.col < 0 || el.col >= ncols ||
+          (symmetric && el.row != el.col && (el.col >= nrows || el.row >= ncols))) {
         range_error = true;
         continue;
       }
+#pragma omp atomic
       rowcnt[el.row + 1]++;
       if (symmetric && el.row != el.col) {
-        if (el.col >= nrows || el.row >= ncols) range_error = true;
-        else rowcnt[el.col + 1]++;
+#pragma omp atomic
+        rowcnt[el.col + 1]++;
       }
     }
   if (range_error) {
@@ -389,14 +400,24 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
   };
   std::vector<CV> buf((size_t)nnz);
   {
+    // a row's bucket is filled in whatever order the threads arrive; `seq` (twice
+    // the file order, +1 for the mirrored copy) restores the file order of equal
+    // columns in the sort below, so the result does not depend on the threads
     std::vector<long> fill(rowcnt.begin(), rowcnt.end() - 1);
-    long seq = 0;
-    seen = 0;
-    for (int i = 0; i < nth && seen < keep; i++)
-      for (size_t k = 0; k < part[i].size() && seen < keep; k++, seen++) {
+#pragma omp parallel for schedule(static, 1) num_threads(nth)
+    for (int i = 0; i < nth; i++)
+      for (size_t k = 0; k < part[i].size(); k++) {
         const Elem &el = part[i][k];
-        buf[fill[el.row]++] = CV{el.col, el.val, seq++};
-        if (symmetric && el.row != el.col) buf[fill[el.col]++] = CV{el.row, el.val, seq++};
+        const long seq = 2 * (base[i] + (long)k);
+        long pos;
+#pragma omp atomic capture
+        pos = fill[el.row]++;
+        buf[pos] = CV{el.col, el.val, seq};
+        if (symmetric && el.row != el.col) {
+#pragma omp atomic capture
+          pos = fill[el.col]++;
+          buf[pos] = CV{el.row, el.val, seq + 1};
+        }
       }
     for (auto &v : part) std::vector<Elem>().swap(v);
   }
