@@ -1072,8 +1072,12 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     delete m;
     return rc;
   }
+  // kept until the window-shape step below has had its chance to reuse it
+  cfs_plan::ScheduleSpace<V> space;
+  const bool want_tuning = !(opt && (opt->flags & CFS_HIP_FLAG_NO_CALIBRATE));
   if (!cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                               nranks > 1 ? row_splits : nullptr, po, m->P)) {
+                               nranks > 1 ? row_splits : nullptr, po, m->P,
+                               want_tuning ? &space : nullptr)) {
     std::string e = m->P.error;
     delete m;
     return set_err(CFS_HIP_ERR_UNSUPPORTED, e);
@@ -1120,8 +1124,9 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     float t_def = 0, t_alt = 0;
     bool ok = query_residency<V>(po2) == 0 &&
               cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                                      nranks > 1 ? row_splits : nullptr, po2, alt->P) &&
+                                      nranks > 1 ? row_splits : nullptr, po2, alt->P, &space) &&
               alt->upload() == 0;
+    space = cfs_plan::ScheduleSpace<V>(); // release the schedule-space matrix
     for (int round = 0; ok && round < 3; round++) { // interleaved, best of three each
       float a = 0, b = 0;
       ok = time_spmv(m, &a) == 0 && time_spmv(alt, &b) == 0;

@@ -988,11 +988,23 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
   }
 }
 
+// The clustered row order of a block and its matrix in schedule space: what a
+// second build of the same rows with HALF as many groups can reuse (tune() tries
+// two window shapes: the clusters of the coarser schedule are pairs of the finer
+// one's, consecutive in the sweep order).
+template <typename V> struct ScheduleSpace {
+  bool valid = false;
+  int rb = 0, re = 0, ngroups = 0;
+  std::vector<int32_t> perm, chunk, brp, bci;
+  std::vector<V> bva;
+};
+
 // Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the full
 // CSR.  Returns false (plan.error set) when the matrix cannot be scheduled.
 template <typename V>
 bool build_plan(int n, const int *rowptr, const int *colind, const V *values, int nranks,
-                int rank, const int *row_splits_in, const Options &opt, SymPlan<V> &P) {
+                int rank, const int *row_splits_in, const Options &opt, SymPlan<V> &P,
+                ScheduleSpace<V> *cache = nullptr) {
   const int rb = row_splits_in ? row_splits_in[rank] : 0;
   const int re = row_splits_in ? row_splits_in[rank + 1] : n;
   const int rows = re - rb;
@@ -1037,8 +1049,23 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   if (ngroups < 8) ngroups = 8;
 
   PhaseTimer pt;
-  std::vector<int32_t> perm, chunk;
   const bool mirror = opt.mirror_offblock && nranks > 1;
+  ScheduleSpace<V> local;
+  ScheduleSpace<V> &sp = cache ? *cache : local;
+  if (cache && cache->valid && cache->rb == rb && cache->re == re && cache->ngroups == 2 * ngroups &&
+      opt.group_share.empty()) {
+    // reuse: same row order, every second cluster boundary; always clustered
+    std::vector<int32_t> merged(ngroups + 1);
+    for (int g = 0; g <= ngroups; g++) merged[g] = sp.chunk[2 * g];
+    pt.lap("schedule space reused");
+    if (build_plan_core<V>(n, sp.brp.data(), sp.bci.data(), sp.bva.data(), nranks, rank,
+                           row_splits_in, opt, &merged, &sp.perm, P))
+      return true;
+    return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
+                              nullptr, nullptr, P);
+  }
+  sp.valid = false;
+  std::vector<int32_t> &perm = sp.perm, &chunk = sp.chunk;
   cluster_rows<V>(n, rowptr, colind, rb, re, ngroups, opt.group_share, perm, chunk, mirror);
   pt.lap("cluster_rows");
   std::vector<int32_t> inv(rows);
@@ -1061,7 +1088,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
       if (colind[j] == lo) return j; // unsorted row
     return -1;
   };
-  std::vector<int32_t> brp((size_t)n + 2, 0);
+  std::vector<int32_t> &brp = sp.brp;
+  brp.assign((size_t)n + 2, 0);
 #pragma omp parallel for schedule(static) num_threads(host_threads())
   for (int p = rb; p < re; p++) {
     const int i = perm[p - rb];
@@ -1075,8 +1103,10 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   }
   for (int p = rb; p < re; p++) brp[p + 1] += brp[p]; // rows < rb are empty
   const int64_t bnnz = brp[re];
-  std::vector<int32_t> bci((size_t)bnnz + 1);
-  std::vector<V> bva((size_t)bnnz + 1);
+  std::vector<int32_t> &bci = sp.bci;
+  std::vector<V> &bva = sp.bva;
+  bci.assign((size_t)bnnz + 1, 0);
+  bva.assign((size_t)bnnz + 1, V(0));
   bool asym = false;
 #pragma omp parallel num_threads(host_threads())
   {
@@ -1162,8 +1192,13 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   }
   if (use_clustered &&
       build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in, opt,
-                         &chunk, &perm, P))
+                         &chunk, &perm, P)) {
+    sp.valid = true; // a later build with half as many groups may reuse it
+    sp.rb = rb;
+    sp.re = re;
+    sp.ngroups = ngroups;
     return true;
+  }
   std::vector<int32_t>().swap(bci);
   std::vector<V>().swap(bva);
   return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
