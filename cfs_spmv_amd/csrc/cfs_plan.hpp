@@ -15,12 +15,14 @@
 //     (own rows first, then the sorted "halo" columns left of the tile), so
 //     the gather x[col] and the transposed update y[col] += a*x[row] both hit
 //     LDS (ds_read / ds_add), and the index stream shrinks from 4 to 2 bytes;
-//   * rows of a tile are sorted by length and stored in 64-row SLICES (lane l
-//     holds row l of the slice) as a uniform stream of 4-diagonal PACKETS laid
-//     out for 16-byte coalesced loads; a packet covers the lanes whose row
-//     still has 4 more entries (a prefix of the lanes, because rows are
-//     sorted), so there is no padding and no special case in the stream.  The
-//     len%4 last entries of every row go to a small per-tile COO section
+//   * rows of a tile are stored in 64-row SLICES (lane l holds row l of the
+//     slice; siblings -- the rows of one mesh node -- stay in one slice, slices
+//     are sorted by length inside) as a uniform stream of 4-diagonal PACKETS
+//     laid out for 16-byte coalesced loads; a packet covers the lanes whose
+//     row still has 4 more entries (a prefix of the lanes), so there is no
+//     padding and no special case in the stream.  A lane whose column sequence
+//     is a prefix of an earlier lane's stores no slots and reads that lane's.
+//     The len%4 last entries of every row go to a small per-tile COO section
 //     (row slot, column slot, value) handled with LDS atomics on both sides;
 //   * conflicts BETWEEN tiles (the reference's direct conflicts, :1443-1451)
 //     are not coloured away but deferred: a tile stores its halo sums to a
@@ -28,7 +30,10 @@
 //     the strips into y through an inverted index in a fixed order (no global
 //     atomics, no barriers between colours);
 //   * tiles are dealt to persistent workgroups in contiguous, cost-balanced
-//     groups, groups of neighbouring rows on the same XCD (blockIdx % 8).
+//     groups, groups of neighbouring rows on the same XCD (blockIdx % 8);
+//   * a 1-D row block of a sharded matrix stores its off-block entries
+//     MIRRORED (both ranks keep them, each processes its side), so that no
+//     contribution leaves the rank and a sharded SpMV needs no exchange.
 #pragma once
 
 #include <omp.h>
