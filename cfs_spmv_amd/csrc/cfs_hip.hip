@@ -1150,7 +1150,9 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   // and the launch is as long as its slowest XCD.  Measure the mean finish time
   // per XCD label with the timeline build of the kernel and re-cut the rows with
   // per-XCD shares; keep the new schedule only if its launches end earlier.
-  if (tuning && m->P.ngroups >= 64) {
+  // (a launch shorter than ~30 us -- fewer than 16M stored nonzeros -- is all start-up
+  // and tail: the XCD shares never paid there, pwtk stand-in 12.0 -> 12.3 us)
+  if (tuning && m->P.ngroups >= 64 && m->P.nnz_low >= (int64_t)16000000) {
     const int G = m->P.ngroups, nper = G >> 3;
     DevBuf xb, yb;
     if ((rc = xb.alloc((size_t)n * sizeof(V))) || (rc = yb.alloc((size_t)m->rows() * sizeof(V)))) {

@@ -87,9 +87,10 @@ typedef struct {
 /* tune() of a matrix with >= 2M stored nonzeros measures: (1) when no block /
  * slot count is given and the rows are scheduled in clustered order, the default
  * window shape (512 threads x 2 workgroups per CU) against 1024 threads x 1 with a
- * window twice the size, keeping the faster; (2) the per-XCD finish times of a
- * few launches, re-cutting the rows with per-XCD work shares (kept only if the
- * launches end earlier).  This flag skips both (one schedule build).          */
+ * window twice the size, keeping the faster; (2) from 16M stored nonzeros, the
+ * per-XCD finish times of a few launches, re-cutting the rows with per-XCD work
+ * shares (kept only if the launches end earlier).  This flag skips both (one
+ * schedule build).                                                            */
 #define CFS_HIP_FLAG_NO_CALIBRATE 32
 /* Shards only.  Default: off-block entries are MIRRORED -- stored by both ranks
  * they touch and processed one-sided, so that no contribution to y ever leaves
