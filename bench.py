@@ -18,6 +18,14 @@ the dominant kernel against the 8 TB/s HBM3E peak in "roofline", and the CPU
 oracle (the reference's OpenMP conflict-free path, restated) timed on this
 box's host cores in "cpu_baseline" (rank 0, N = 1 only).
 
+`python bench.py --gpus N` WITHOUT a torchrun environment (WORLD_SIZE unset) starts
+the N ranks itself: the parent never touches HIP, it spawns
+`python -m torch.distributed.run --nproc-per-node N ... bench.py <same args>` as a
+child process and exits with its code.  At N > 1 the line also carries
+`exchange_forms`: ms_per_step of the three forms of the off-block exchange (none =
+mirrored shards, all_to_all, reduce_scatter = the RCCL collective the north-star
+names), measured in the same run.
+
 Only the cpu_baseline leg imports oracle/ -- as the reported baseline, never as
 the thing measured.
 """
@@ -45,7 +53,11 @@ def parse():
     ap.add_argument("--max-slots", type=int, default=0)
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-loops", type=int, default=32)
+    ap.add_argument("--cpu-loops", type=int, default=128,
+                    help="timed SpMVs of each cpu_baseline leg (the reference driver's protocol: "
+                         "loops/2 warm-up, loops timed; SURVEY 8d asks for 128)")
+    ap.add_argument("--no-exchange-forms", action="store_true",
+                    help="N>1: skip the extra timings of the other two exchange forms")
     ap.add_argument("--exchange", default="none", choices=["none", "all_to_all", "reduce_scatter"],
                     help="N>1: 'none' = mirrored shards, every off-block entry is stored by both "
                          "ranks it touches and no SpMV needs a collective (default); "
@@ -74,8 +86,14 @@ def host_cpus():
 
 
 def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
-    """the oracle's restatement of cpu_mv_sym_conflict_free_v2 on the host cores,
-    same matrix, same x, reference protocol (loops/2 warm-up, loops timed)"""
+    """the oracle's restatement of the reference's two CPU paths on the host cores,
+    same matrix, same x, reference protocol (loops/2 warm-up, loops timed,
+    bench/bench_spmv_mmf.cpp:154-167): cpu_mv_sym_conflict_free_v2
+    (csr_matrix.tpp:2965-3028; `value`) and plain CSR cpu_mv (:2683-2704; `csr`).
+    OMP_PLACES=cores OMP_PROC_BIND=close are set by main() before any OpenMP runtime
+    is loaded."""
+    import ctypes as C
+    import numpy as np
     from oracle import oracle
     T = max(1, min(host_cpus(), 96))  # MaxThreads = 96, include/utils/runtime.hpp:15
     t0 = time.time()
@@ -90,18 +108,126 @@ def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
     dt = (time.time() - t0) / loops
     info = o.info()
     o.close()
+    # plain CSR leg: cpu_mv over partition_by_nnz (tune(Aggressive), csr_matrix.tpp:250-254)
+    L = oracle.lib()
+    suf = "f64" if va.dtype == np.float64 else "f32"
+    rs = oracle.partition_by_nnz(n, rp, T)
+    f = getattr(L, "orc_csr_spmv_" + suf)
+    xs = np.ascontiguousarray(x_host, va.dtype)
+    args = (n, rp.ctypes.data, ci.ctypes.data, va.ctypes.data, T, rs.ctypes.data,
+            y.ctypes.data, xs.ctypes.data)
+    for _ in range(loops // 2):
+        f(*args)
+    t0 = time.time()
+    for _ in range(loops):
+        f(*args)
+    dt_csr = (time.time() - t0) / loops
+    s = va.itemsize
     return {
         "value": round(2.0 * nnz_full / dt / 1e9, 2), "unit": "GFLOP/s", "cores": T,
         "kind": "port",
-        "sample": f"whole workload: {loops // 2} warm-up + {loops} timed SpMVs of the "
-                  f"oracle's conflict-free v2 path ({info['ncolors']} colours), "
-                  f"preproc {preproc:.1f}s, {dt * 1e3:.2f} ms/SpMV",
+        "sample": f"whole workload, OMP_PLACES=cores OMP_PROC_BIND=close: {loops // 2} warm-up + "
+                  f"{loops} timed SpMVs of the oracle's conflict-free v2 path "
+                  f"({info['ncolors']} colours), {dt * 1e3:.2f} ms/SpMV; same protocol for the "
+                  f"plain-CSR cpu_mv leg, {dt_csr * 1e3:.2f} ms/SpMV.  The oracle's preprocessing "
+                  f"({preproc:.1f}s) skips the indirect-conflict scan of rows whose upper entries "
+                  f"stay in one thread, an early-out the reference does not have: it is NOT the "
+                  f"reference's preprocessing time",
         "ms_per_step": round(dt * 1e3, 3),
+        "csr": {"value": round(2.0 * nnz_full / dt_csr / 1e9, 2), "unit": "GFLOP/s",
+                "ms_per_step": round(dt_csr * 1e3, 3),
+                "effective_GBps": round((nnz_full * (4 + s) + n * (4 + 2 * s)) / dt_csr / 1e9, 1)},
+        "effective_GBps": round(((nnz_full - n) // 2 * (4 + s) + n * (4 + 3 * s)) / dt / 1e9, 1),
     }
+
+
+def time_other_forms(args, cfs, A, sh, n, rp, ci, va, N, rank, rs, dev, opt, backend, x, y,
+                     stream, barrier, dist):
+    """ms_per_step (max over ranks, K steps between barriers) of the exchange forms the
+    main run did not use.  "none" = mirrored shards (no collective), "all_to_all" = packed
+    contributions, one sparse all-to-all, "reduce_scatter" = one RCCL
+    reduce_scatter_tensor(sum) over padded blocks (the north-star's form).  A form that
+    cannot run reports its error text instead of a number; the main line is unaffected."""
+    import torch
+    from cfs_spmv_amd import _lib
+    from cfs_spmv_amd.dist import ShardedSym, build_shard
+    from cfs_spmv_amd.matrix import FLAG_SHARD_EXCHANGE
+    out = {}
+    K, W = args.steps, max(5, args.warmup // 2)
+    handles = {}
+
+    def timed(step):
+        for _ in range(W):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        barrier()
+        el = time.perf_counter() - t0
+        t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return round(float(t.item()) / K * 1e3, 5)
+
+    for form in ("none", "all_to_all", "reduce_scatter"):
+        if form == args.exchange:
+            continue
+        try:
+            if form == "none":
+                A2, sh2, used = build_shard(n, rp, ci, va, N, rank, rs, dev, options=opt,
+                                            exchange="none", stage_via_host=(backend != "nccl"))
+                if used != "none":
+                    out[form] = "not mirrorable: fell back to all_to_all"
+                    A2.close()
+                    continue
+                handles["none"] = A2
+            else:
+                # both exchange forms share ONE handle built with CFS_HIP_FLAG_SHARD_EXCHANGE
+                A2 = handles.get("x") or (A if args.exchange != "none" else None)
+                if A2 is None:
+                    A2 = cfs.SymMatrix(n, rp, ci, va, options=_lib.Options(
+                        opt.max_slots, opt.max_tile_nnz, opt.block_threads,
+                        opt.flags | FLAG_SHARD_EXCHANGE), row_splits=rs, rank=rank)
+                    handles["x"] = A2
+                sh2 = ShardedSym(A2, N, rank, va.dtype, dev, stage_via_host=(backend != "nccl"),
+                                 exchange=form, row_splits=rs)
+            out[form] = timed(lambda: sh2.spmv(y, x))
+        except Exception as e:  # reported, never fatal for the main number
+            out[form] = f"failed: {type(e).__name__}: {e}"[:200]
+    torch.cuda.synchronize()
+    for h in handles.values():
+        h.close()
+    return out
+
+
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args):
+    """--gpus N without a torchrun environment: start the N ranks as a CHILD process
+    (the parent has not touched the GPU and never does) and pass its exit code on"""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    print(f"[bench] WORLD_SIZE unset: launching {args.gpus} ranks: {' '.join(cmd)}",
+          file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("CFS_FORCE_DIST") != "1":
+        raise SystemExit(self_launch(args))
+    # the CPU baseline's binding (SURVEY 8d); must precede the first OpenMP runtime
+    os.environ.setdefault("OMP_PLACES", "cores")
+    os.environ.setdefault("OMP_PROC_BIND", "close")
     # host-side setup (matrix generator, schedule build) is OpenMP code: give every
     # rank of this node an equal share of the CPUs (torchrun presets
     # OMP_NUM_THREADS=1 for N > 1, which would serialise it).  Set before any
@@ -266,14 +392,19 @@ def main():
 
     alg_bytes = st["bytes_algorithmic"]  # this rank's rows: nnz_low*(4+s) + rows*(4+3s)
     achieved = alg_bytes / (tile_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes (profiles/hbm_traffic.json, written by
+    # tools/profile_round.sh): only quoted when the entry was measured on the SAME
+    # schedule that ran here (bytes the format streams, tiles, window, block) -- a
+    # stale entry reads null, never a number of another kernel
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            key = f"{args.matrix}:{args.scale}:{args.dtype}:{N}"
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            ent = tj.get(f"{args.matrix}:{args.scale}:{args.dtype}:{N}", {})
+            same = all(ent.get(k) == st[k] for k in ("bytes_streamed", "lds_bytes", "block_threads"))
+            traffic = ent.get("hbm_bytes_per_launch") if same else None
         except Exception:
             traffic = None
 
@@ -322,14 +453,41 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(tile_ms, 5), "kernel_samples": len(sampled),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
+                # `achieved` is ALGORITHMIC bytes / kernel time (the device format streams
+                # fewer: 16-bit de-duplicated slots); what really crossed the HBM interface:
+                "hbm_GBps_from_traffic": (round(traffic / (tile_ms * 1e-3) / 1e9, 1)
+                                          if traffic else None),
+                "bytes_streamed_by_format": int(st["bytes_streamed"]),
             },
         }
+
     if rank == 0 and N == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(n, rp, ci, va, x_host, nnz_full, args.cpu_loops)
         except Exception as e:  # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0,
                                    "kind": "port", "sample": f"failed: {e}"}
+    # ---- N > 1: the other forms of the off-block exchange, same run, same protocol.
+    # Measured LAST, under a watchdog: whatever happens to them (a collective that
+    # hangs on some stack), the ONE line of the contract is printed.
+    if sh is not None and not args.no_exchange_forms:
+        import threading
+
+        def give_up():
+            if rank == 0:
+                out["exchange_forms"] = {args.exchange: round(ms_per_step, 5),
+                                         "others": "timed out after 120 s"}
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+        dog = threading.Timer(120.0, give_up)
+        dog.daemon = True
+        dog.start()
+        forms = {args.exchange: round(ms_per_step, 5)}
+        forms.update(time_other_forms(args, cfs, A, sh, n, rp, ci, va, N, rank, rs, dev, opt,
+                                      backend, x, y, stream, barrier, dist))
+        dog.cancel()
+        if rank == 0:
+            out["exchange_forms"] = forms
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

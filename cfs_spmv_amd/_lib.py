@@ -8,7 +8,10 @@ _LIB = None
 
 
 class CfsHipError(RuntimeError):
-    pass
+    code = 0
+
+
+ERR_ARG, ERR_DEVICE, ERR_UNSUPPORTED, ERR_NOMEM, ERR_INTERNAL, ERR_MIRROR = -1, -2, -3, -4, -5, -6
 
 
 class Options(C.Structure):
@@ -44,13 +47,13 @@ class PlanReport(C.Structure):
 # every symbol include/cfs_hip.h declares (tests check the .so exports them all)
 SYMBOLS = [
     "cfs_hip_abi_version", "cfs_hip_last_error", "cfs_hip_device_count", "cfs_hip_init",
-    "cfs_hip_default_stream", "cfs_hip_synchronize", "cfs_hip_alloc", "cfs_hip_free",
+    "cfs_hip_current_device", "cfs_hip_pinned_owns", "cfs_hip_pinned_pool_stats", "cfs_hip_default_stream", "cfs_hip_synchronize", "cfs_hip_alloc", "cfs_hip_free",
     "cfs_hip_memcpy", "cfs_hip_memset", "cfs_hip_sym_create_f64", "cfs_hip_sym_create_f32",
     "cfs_hip_sym_create_shard_f64", "cfs_hip_sym_create_shard_f32",
     "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_spmv",
     "cfs_hip_sym_spmv_async", "cfs_hip_sym_shard_send_counts", "cfs_hip_sym_shard_send_rows",
     "cfs_hip_sym_shard_set_recv", "cfs_hip_sym_spmv_local_async",
-    "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_plan_check_f64",
+    "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_debug_group_features", "cfs_hip_sym_plan_check_f64",
     "cfs_hip_sym_plan_check_f32", "cfs_hip_sym_plan_send_info_f64", "cfs_hip_csr_create_f64", "cfs_hip_csr_create_f32",
     "cfs_hip_csr_spmv", "cfs_hip_csr_spmv_async", "cfs_hip_csr_destroy",
     "cfs_hip_event_create", "cfs_hip_event_record", "cfs_hip_event_elapsed_ms",
@@ -80,6 +83,9 @@ def load():
     lib.cfs_hip_last_error.restype = C.c_char_p
     lib.cfs_hip_alloc.argtypes = [C.c_size_t, C.c_int, C.POINTER(vp)]
     lib.cfs_hip_free.argtypes = [vp, C.c_int]
+    lib.cfs_hip_current_device.argtypes = [ip]
+    lib.cfs_hip_pinned_owns.argtypes = [vp]
+    lib.cfs_hip_pinned_pool_stats.argtypes = [C.POINTER(C.c_size_t)] * 3
     lib.cfs_hip_memcpy.argtypes = [vp, vp, C.c_size_t, C.c_int]
     lib.cfs_hip_memset.argtypes = [vp, C.c_int, C.c_size_t]
     lib.cfs_hip_default_stream.argtypes = [C.POINTER(vp)]
@@ -108,6 +114,7 @@ def load():
     lib.cfs_hip_sym_spmv_phases_async.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     lib.cfs_hip_sym_get_stats.argtypes = [vp, C.POINTER(SymStats)]
     lib.cfs_hip_sym_debug_timeline.argtypes = [vp, vp, vp, vp, C.c_int, ip]
+    lib.cfs_hip_sym_debug_group_features.argtypes = [vp, vp, C.c_int, ip]
     lib.cfs_hip_csr_spmv.argtypes = [vp, vp, vp]
     lib.cfs_hip_csr_spmv_async.argtypes = [vp, vp, vp, vp]
     lib.cfs_hip_csr_destroy.argtypes = [vp]
@@ -122,4 +129,6 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().cfs_hip_last_error().decode(errors="replace")
-        raise CfsHipError(f"cfs_hip error {rc}: {msg}")
+        e = CfsHipError(f"cfs_hip error {rc}: {msg}")
+        e.code = rc
+        raise e

@@ -13,37 +13,39 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
 #include "cfs_hip.h"
 #include "cfs_plan.hpp"
+#include "cfs_runtime.hpp"
 
 using cfs_plan::SymPlan;
 using cfs_plan::Tile;
 
 // ---------------------------------------------------------------------------
-// error plumbing
+// runtime (cfs_runtime.hpp): per-device contexts, pools, error plumbing
 // ---------------------------------------------------------------------------
-static thread_local std::string g_err;
-static int set_err(int code, const std::string &msg) {
-  g_err = msg;
-  return code;
-}
-#define HIPCHK(expr)                                                          \
-  do {                                                                        \
-    hipError_t e__ = (expr);                                                  \
-    if (e__ != hipSuccess)                                                    \
-      return set_err(CFS_HIP_ERR_DEVICE, std::string(#expr) + ": " +          \
-                                             hipGetErrorString(e__));         \
-  } while (0)
+using cfs_rt::DevBuf;
+using cfs_rt::DeviceGuard;
+using cfs_rt::PinBuf;
+using cfs_rt::set_err;
 
-static int g_device = -1;
-static hipStream_t g_stream = nullptr;
+static int ensure_init() { return cfs_rt::ensure_home(); }
 
-static int ensure_init() {
-  if (g_device >= 0) return 0;
-  return cfs_hip_init(0);
+void cfs_rt::parallel_copy(void *dst, const void *src, size_t bytes) {
+  const int T = cfs_plan::host_threads();
+  if (bytes < ((size_t)1 << 20) || T < 2) {
+    memcpy(dst, src, bytes);
+    return;
+  }
+  const size_t chunk = ((bytes + T - 1) / T + 4095) & ~(size_t)4095;
+#pragma omp parallel for schedule(static) num_threads(T)
+  for (int t = 0; t < T; t++) {
+    const size_t b = (size_t)t * chunk;
+    if (b < bytes) memcpy((char *)dst + b, (const char *)src + b, std::min(chunk, bytes - b));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -622,26 +624,21 @@ __global__ void __launch_bounds__(256)
 // ---------------------------------------------------------------------------
 // host objects
 // ---------------------------------------------------------------------------
-struct DevBuf {
-  void *p = nullptr;
-  size_t bytes = 0;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  int upload(const void *src, size_t n) {
-    bytes = n;
-    n += 64; // padding: clamped / one-past-the-end reads of the kernels stay inside
-    HIPCHK(hipMalloc(&p, n));
-    if (bytes) HIPCHK(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
-    return 0;
-  }
-  int alloc(size_t n) {
-    bytes = n;
-    if (n == 0) n = 16;
-    HIPCHK(hipMalloc(&p, n));
-    return 0;
-  }
-};
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the kernel FUNCTION (one
+// template instantiation, per device), not to a handle: two handles with different
+// windows share instantiations.  Every instantiation is raised ONCE per device to
+// the ceiling of a CU (160 KiB minus the static ticket counter) and never lowered.
+static int raise_lds_limit(const void *kernel, int device) {
+  static std::mutex mu;
+  static std::vector<std::pair<const void *, int>> done;
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto &d : done)
+    if (d.first == kernel && d.second == device) return 0;
+  HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             160 * 1024 - 64));
+  done.push_back({kernel, device});
+  return 0;
+}
 
 // fold records {dst, e0, e1, e2 | -(offset + 2)} and the remainder lists
 // [count, entries 2..] of destinations with more than three contributions
@@ -663,6 +660,71 @@ static void make_fold_records(const std::vector<int32_t> &dst, const std::vector
   }
 }
 
+// staging of a handle for callers that pass HOST pointers (the reference's API
+// hands raw host pointers every call, include/kernel/sparse_kernel.hpp:22-23):
+// device mirrors of x / y, and page-locked blocks from the pinned pool
+// (CFS_HIP_MEM_PINNED, allocated once per handle) that pageable vectors are
+// copied through with all host threads.  A vector that already lives in
+// page-locked memory (internal_alloc(.., Platform::cpu) of this build hands such
+// blocks out) is DMA-ed in place.
+struct HostStage {
+  DevBuf xdev, ydev;
+  PinBuf xpin, ypin;
+};
+
+// y <- launch(x) for x / y that may be host or device pointers, on `device`'s
+// library stream.  Returns after the result is complete when host memory is
+// involved; with both vectors resident the work is only enqueued.
+template <class Launch>
+static int run_staged(int device, HostStage &S, size_t xbytes, size_t ybytes, void *y,
+                      const void *x, Launch launch) {
+  cfs_rt::DevCtx *ctx;
+  int rc = cfs_rt::device_ctx(device, &ctx);
+  if (rc) return rc;
+  hipStream_t st = ctx->stream;
+  DeviceGuard g(device);
+  const cfs_rt::PtrInfo xi = cfs_rt::classify(x), yi = cfs_rt::classify(y);
+  if ((xi.device && xi.dev != device) || (yi.device && yi.dev != device))
+    return set_err(CFS_HIP_ERR_ARG, "x / y live on device " +
+                                        std::to_string(xi.device && xi.dev != device ? xi.dev : yi.dev) +
+                                        ", the matrix on device " + std::to_string(device));
+  const void *xdev = x;
+  void *ydev = y;
+  if (!xi.device) {
+    if (S.xdev.bytes < xbytes && (rc = S.xdev.alloc(xbytes))) return rc;
+    const void *src = x;
+    if (!xi.pinned) { // pageable: through the handle's page-locked block
+      if ((rc = S.xpin.reserve(xbytes))) return rc;
+      cfs_rt::parallel_copy(S.xpin.p, x, xbytes);
+      src = S.xpin.p;
+    }
+    HIPCHK(hipMemcpyAsync(S.xdev.p, src, xbytes, hipMemcpyHostToDevice, st));
+    xdev = S.xdev.p;
+  }
+  if (!yi.device) {
+    if (S.ydev.bytes < ybytes && (rc = S.ydev.alloc(ybytes))) return rc;
+    ydev = S.ydev.p;
+  }
+  if ((rc = launch(ydev, xdev, st))) return rc;
+  if (!yi.device) {
+    if (yi.pinned) {
+      HIPCHK(hipMemcpyAsync(y, ydev, ybytes, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    } else {
+      if ((rc = S.ypin.reserve(ybytes))) return rc;
+      HIPCHK(hipMemcpyAsync(S.ypin.p, ydev, ybytes, hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+      cfs_rt::parallel_copy(y, S.ypin.p, ybytes);
+    }
+  } else if (!xi.device) {
+    HIPCHK(hipStreamSynchronize(st)); // the staged x may be overwritten by the next call
+  }
+  // both resident: enqueued on the library stream (a BLOCKING stream: a caller's
+  // own hipMemcpy / hipDeviceSynchronize on the null stream orders behind it, and
+  // so do cfs_hip_memcpy / cfs_hip_synchronize)
+  return 0;
+}
+
 struct cfs_hip_sym_s {
   int value_bytes = 8;
   virtual ~cfs_hip_sym_s() {}
@@ -675,8 +737,11 @@ struct cfs_hip_sym_s {
   virtual int n() = 0;
   virtual int rows() = 0;
   virtual int timeline(void *y, const void *x, unsigned long long *host, int cap, int *ngroups) = 0;
-  // staging for host-pointer callers
-  DevBuf xstage, ystage;
+  virtual int group_features(long long *out, int cap, int *ngroups) = 0;
+  int device = 0; // the device this handle's arrays live on (current device at create)
+  HostStage stage; // host-pointer callers
+  // the last (y, x) pair whose placement was validated (async entry points)
+  const void *ok_x = nullptr, *ok_y = nullptr;
 };
 
 template <typename V> struct SymMatrix : cfs_hip_sym_s {
@@ -792,14 +857,10 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u);
     }
   }
-  const void *raised = nullptr; // instantiation whose dynamic-LDS limit has been raised (lazily, at launch)
-
   int launch_tiles(V *y, const V *x, hipStream_t st) {
     const void *k = tile_kernel();
-    if (k != raised) {
-      HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-      raised = k;
-    }
+    int rc = raise_lds_limit(k, device);
+    if (rc) return rc;
     void *args[] = {(void *)&dev.tiles, (void *)&dev.gfirst, (void *)&dev.group_ptr,
                     (void *)&dev.slot_col, (void *)&dev.rowinfo, (void *)&dev.diag,
                     (void *)&dev.slice_meta, (void *)&dev.leadlane, (void *)&dev.vals,
@@ -908,6 +969,31 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     HIPCHK(hipMemcpy(host, b.p, b.bytes, hipMemcpyDeviceToHost));
     return 0;
   }
+  // per persistent group, kCfsGroupFeatures words (cfs_hip_sym_debug_group_features)
+  int group_features(long long *out, int cap, int *ng) override {
+    *ng = P.ngroups;
+    if (cap < P.ngroups * CFS_HIP_GROUP_FEATURES)
+      return set_err(CFS_HIP_ERR_ARG, "buffer too small");
+    const int T = (int)P.tiles.size();
+    for (int g = 0; g < P.ngroups; g++) {
+      long long *o = out + (size_t)g * CFS_HIP_GROUP_FEATURES;
+      for (int k = 0; k < CFS_HIP_GROUP_FEATURES; k++) o[k] = 0;
+      for (int ti = P.group_ptr[g]; ti < P.group_ptr[g + 1]; ti++) {
+        const Tile &t = P.tiles[ti];
+        o[0] += 1;
+        o[1] += t.nown;
+        o[2] += t.nvrows;
+        o[3] += t.nslices;
+        o[4] += ti < (int)P.tile_rounds.size() ? P.tile_rounds[ti] : 0;
+        o[5] += (ti + 1 < T ? P.tiles[ti + 1].nnz_off : stream_len) - t.nnz_off;
+        o[6] += (ti + 1 < T ? P.tiles[ti + 1].sl_off : slot_len) - t.sl_off;
+        o[7] += t.ncoo;
+        o[8] += t.nslots - t.nown;
+        o[9] += t.nslots;
+      }
+    }
+    return 0;
+  }
   int n() override { return P.n; }
   int rows() override { return P.row_end - P.row_begin; }
 };
@@ -915,7 +1001,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
 struct cfs_hip_csr_s {
   int value_bytes = 8, nrows = 0, ncols = 0, nblocks = 0;
   int64_t nnz = 0;
-  DevBuf rowptr, colind, values, blk_row, xstage, ystage;
+  DevBuf rowptr, colind, values, blk_row;
+  HostStage stage;
+  int device = 0;
 };
 
 // ---------------------------------------------------------------------------
@@ -923,7 +1011,7 @@ struct cfs_hip_csr_s {
 // ---------------------------------------------------------------------------
 
 int cfs_hip_abi_version(void) { return CFS_HIP_ABI_VERSION; }
-const char *cfs_hip_last_error(void) { return g_err.c_str(); }
+const char *cfs_hip_last_error(void) { return cfs_rt::last_error().c_str(); }
 
 int cfs_hip_device_count(int *count) {
   if (!count) return set_err(CFS_HIP_ERR_ARG, "count is NULL");
@@ -937,30 +1025,42 @@ int cfs_hip_device_count(int *count) {
   return 0;
 }
 
-int cfs_hip_init(int device) {
-  if (g_device == device && g_stream) return 0;
-  HIPCHK(hipSetDevice(device));
-  if (g_stream) {
-    (void)hipStreamDestroy(g_stream);
-    g_stream = nullptr;
-  }
-  HIPCHK(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-  g_device = device;
+// Make `device` the calling thread's current device and the home of the
+// synchronous entry points.  Contexts (streams) of other devices stay alive:
+// handles created on them keep working.
+int cfs_hip_init(int device) { return cfs_rt::bind_home(device); }
+
+int cfs_hip_current_device(int *device) {
+  if (!device) return set_err(CFS_HIP_ERR_ARG, "device is NULL");
+  int rc = ensure_init();
+  if (rc) return rc;
+  *device = cfs_rt::rt().home;
   return 0;
 }
 
 int cfs_hip_default_stream(void **stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  *stream = (void *)g_stream;
+  *stream = (void *)cfs_rt::home_stream();
   return 0;
 }
 
 int cfs_hip_synchronize(void *stream) {
   int rc = ensure_init();
   if (rc) return rc;
-  // NULL: the library stream of the synchronous entry points
-  HIPCHK(hipStreamSynchronize(stream ? (hipStream_t)stream : g_stream));
+  if (stream) {
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+  }
+  // NULL: the library streams of the synchronous entry points, on every device
+  // a handle of this process lives on (a matrix sharded over N GPUs by the C++
+  // surface runs on N of them)
+  for (int d = 0; d < cfs_rt::kMaxDevices; d++) {
+    hipStream_t st = cfs_rt::rt().ctx[d].stream;
+    if (!st) continue;
+    DeviceGuard g(d);
+    HIPCHK(hipStreamSynchronize(st));
+  }
   return 0;
 }
 
@@ -969,17 +1069,33 @@ int cfs_hip_alloc(size_t bytes, int kind, void **out) {
   int rc = ensure_init();
   if (rc) return rc;
   if (bytes == 0) bytes = 64;
-  if (kind == CFS_HIP_MEM_DEVICE) HIPCHK(hipMalloc(out, bytes));
-  else if (kind == CFS_HIP_MEM_PINNED) HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
-  else return set_err(CFS_HIP_ERR_ARG, "unknown memory kind");
+  if (kind == CFS_HIP_MEM_DEVICE) {
+    DeviceGuard g(cfs_rt::rt().home);
+    HIPCHK(hipMalloc(out, bytes));
+  } else if (kind == CFS_HIP_MEM_PINNED) {
+    return cfs_rt::pinned().alloc(bytes, out);
+  } else {
+    return set_err(CFS_HIP_ERR_ARG, "unknown memory kind");
+  }
   return 0;
 }
 
 int cfs_hip_free(void *p, int kind) {
   if (!p) return 0;
   if (kind == CFS_HIP_MEM_DEVICE) HIPCHK(hipFree(p));
-  else if (kind == CFS_HIP_MEM_PINNED) HIPCHK(hipHostFree(p));
+  else if (kind == CFS_HIP_MEM_PINNED) return cfs_rt::pinned().release(p);
   else return set_err(CFS_HIP_ERR_ARG, "unknown memory kind");
+  return 0;
+}
+
+int cfs_hip_pinned_owns(const void *p) { return p && cfs_rt::pinned().owns(p) ? 1 : 0; }
+
+int cfs_hip_pinned_pool_stats(size_t *live_blocks, size_t *spare_blocks, size_t *spare_bytes) {
+  size_t a = 0, b = 0, c = 0;
+  cfs_rt::pinned().stats(&a, &b, &c);
+  if (live_blocks) *live_blocks = a;
+  if (spare_blocks) *spare_blocks = b;
+  if (spare_bytes) *spare_bytes = c;
   return 0;
 }
 
@@ -989,7 +1105,7 @@ int cfs_hip_memcpy(void *dst, const void *src, size_t bytes, int dir) {
   hipMemcpyKind k = dir == CFS_HIP_H2D   ? hipMemcpyHostToDevice
                     : dir == CFS_HIP_D2H ? hipMemcpyDeviceToHost
                                          : hipMemcpyDeviceToDevice;
-  if (g_stream) HIPCHK(hipStreamSynchronize(g_stream)); // pending SpMVs on resident vectors
+  if ((rc = cfs_hip_synchronize(nullptr))) return rc; // pending SpMVs on resident vectors
   HIPCHK(hipMemcpy(dst, src, bytes, k));
   return 0;
 }
@@ -997,6 +1113,18 @@ int cfs_hip_memcpy(void *dst, const void *src, size_t bytes, int dir) {
 int cfs_hip_memset(void *dst, int value, size_t bytes) {
   HIPCHK(hipMemset(dst, value, bytes));
   return 0;
+}
+
+// what a refusal of the schedule builder means to the caller.  UNSUPPORTED is
+// reserved for matrices the tile schedule does not cover (a row denser than an LDS
+// window, 16-/25-/31-bit offsets exhausted): src/csr.cpp then binds the general CSR
+// kernel.  Bad arguments, the mirror refusals of a shard and builder bugs get codes
+// of their own -- they must never turn into a quietly slower path.
+static int plan_error_code(const std::string &e) {
+  if (e.rfind("mirror:", 0) == 0) return CFS_HIP_ERR_MIRROR;
+  if (e.rfind("internal:", 0) == 0) return CFS_HIP_ERR_INTERNAL;
+  if (e.rfind("bad ", 0) == 0 || e.rfind("block_threads", 0) == 0) return CFS_HIP_ERR_ARG;
+  return CFS_HIP_ERR_UNSUPPORTED;
 }
 
 static cfs_plan::Options to_opts(const cfs_hip_options *o) {
@@ -1025,7 +1153,10 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
 // run as a second round and double the launch time)
 template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
   const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true, true, cfs_plan::kSlotsPerThread>;
-  HIPCHK(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  int rc = raise_lds_limit(k, dev);
+  if (rc) return rc;
   HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(nb, k, BLOCK, lds));
   return 0;
 }
@@ -1046,7 +1177,9 @@ template <typename V> static int query_residency(cfs_plan::Options &po) {
   }
   if (rc) return rc;
   hipDeviceProp_t prop;
-  HIPCHK(hipGetDeviceProperties(&prop, g_device));
+  int dev = 0;
+  HIPCHK(hipGetDevice(&dev));
+  HIPCHK(hipGetDeviceProperties(&prop, dev));
   po.wg_per_cu = nb > 0 ? nb : 1;
   po.num_cus = prop.multiProcessorCount;
   return 0;
@@ -1065,8 +1198,11 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   if (nranks > 1 && !row_splits) return set_err(CFS_HIP_ERR_ARG, "row_splits required");
   int rc = ensure_init();
   if (rc) return rc;
+  int cur_dev = 0;
+  HIPCHK(hipGetDevice(&cur_dev));
   auto *m = new SymMatrix<V>();
   m->value_bytes = (int)sizeof(V);
+  m->device = cur_dev;
   cfs_plan::Options po = to_opts(opt);
   if ((rc = query_residency<V>(po))) {
     delete m;
@@ -1080,7 +1216,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
                                want_tuning ? &space : nullptr)) {
     std::string e = m->P.error;
     delete m;
-    return set_err(CFS_HIP_ERR_UNSUPPORTED, e);
+    return set_err(plan_error_code(e), e);
   }
   rc = m->upload();
   if (rc) {
@@ -1121,6 +1257,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     po2.max_slots = 2 * cfs_plan::kDefaultSlots;
     auto *alt = new SymMatrix<V>();
     alt->value_bytes = (int)sizeof(V);
+    alt->device = cur_dev;
     float t_def = 0, t_alt = 0;
     bool ok = query_residency<V>(po2) == 0 &&
               cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
@@ -1189,6 +1326,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
       for (int g = 0; g < G; g++) po.group_share[g] = mean / e0[g / nper]; // slow XCD: less work
       auto *nx = new SymMatrix<V>();
       nx->value_bytes = (int)sizeof(V);
+      nx->device = cur_dev;
       double e1[8], k1 = 0;
       if (cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
                                   nranks > 1 ? row_splits : nullptr, po, nx->P) &&
@@ -1242,47 +1380,43 @@ int cfs_hip_sym_destroy(cfs_hip_sym_t h) {
   return 0;
 }
 
-static bool is_device_ptr(const void *p) {
-  hipPointerAttribute_t a;
-  hipError_t e = hipPointerGetAttributes(&a, p);
-  if (e != hipSuccess) {
-    (void)hipGetLastError(); // unregistered host memory: clear the sticky error
-    return false;
-  }
-  return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+// the async entry points take device pointers on the caller's stream; the
+// placement of a (y, x) pair is checked once (hipPointerGetAttributes costs more
+// than the launch): vectors on another device than the matrix would fault or, with
+// peer access, silently run over the fabric
+static int check_placement(cfs_hip_sym_t h, const void *y, const void *x) {
+  if (h->ok_x == x && h->ok_y == y) return 0;
+  const cfs_rt::PtrInfo xi = cfs_rt::classify(x), yi = cfs_rt::classify(y);
+  if (!xi.device || !yi.device)
+    return set_err(CFS_HIP_ERR_ARG, "async entry points need device pointers (use cfs_hip_sym_spmv)");
+  if (xi.dev != h->device || yi.dev != h->device)
+    return set_err(CFS_HIP_ERR_ARG, "x / y live on device " +
+                                        std::to_string(xi.dev != h->device ? xi.dev : yi.dev) +
+                                        ", the matrix on device " + std::to_string(h->device));
+  h->ok_x = x;
+  h->ok_y = y;
+  return 0;
 }
 
 int cfs_hip_sym_spmv_async(cfs_hip_sym_t h, void *y, const void *x, void *stream) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
   if (!h->send_rows().empty())
     return set_err(CFS_HIP_ERR_ARG, "sharded handle: use cfs_hip_sym_spmv_local_async");
+  int rc = check_placement(h, y, x);
+  if (rc) return rc;
+  DeviceGuard g(h->device);
   return h->spmv_local(y, x, nullptr, (hipStream_t)stream);
 }
 
 int cfs_hip_sym_spmv(cfs_hip_sym_t h, void *y, const void *x) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  if (!h->send_rows().empty())
+    return set_err(CFS_HIP_ERR_ARG, "sharded handle: use cfs_hip_sym_spmv_local_async");
   const size_t vb = (size_t)h->value_bytes;
-  const bool xd = is_device_ptr(x), yd = is_device_ptr(y);
-  const void *xdev = x;
-  void *ydev = y;
-  int rc;
-  if (!xd) { // slow staged path for drop-in host-pointer callers
-    if (!h->xstage.p && (rc = h->xstage.alloc((size_t)h->n() * vb))) return rc;
-    HIPCHK(hipMemcpyAsync(h->xstage.p, x, (size_t)h->n() * vb, hipMemcpyHostToDevice, g_stream));
-    xdev = h->xstage.p;
-  }
-  if (!yd) {
-    if (!h->ystage.p && (rc = h->ystage.alloc((size_t)h->rows() * vb))) return rc;
-    ydev = h->ystage.p;
-  }
-  if ((rc = cfs_hip_sym_spmv_async(h, ydev, xdev, g_stream))) return rc;
-  if (!yd)
-    HIPCHK(hipMemcpyAsync(y, ydev, (size_t)h->rows() * vb, hipMemcpyDeviceToHost, g_stream));
-  // host memory involved: the result must be usable on return.  Device-resident
-  // x and y: the work is ordered on the library stream and the caller observes
-  // it through cfs_hip_memcpy / cfs_hip_synchronize (both wait for this stream).
-  if (!xd || !yd) HIPCHK(hipStreamSynchronize(g_stream));
-  return 0;
+  return run_staged(h->device, h->stage, (size_t)h->n() * vb, (size_t)h->rows() * vb, y, x,
+                    [&](void *yd, const void *xd, hipStream_t st) {
+                      return h->spmv_local(yd, xd, nullptr, st);
+                    });
 }
 
 int cfs_hip_sym_shard_send_counts(cfs_hip_sym_t h, int *send_counts) {
@@ -1304,15 +1438,22 @@ int cfs_hip_sym_shard_set_recv(cfs_hip_sym_t h, int nrecv, const int *recv_rows)
 int cfs_hip_sym_spmv_local_async(cfs_hip_sym_t h, void *y, const void *x, void *send,
                                  void *stream) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  int rc = check_placement(h, y, x);
+  if (rc) return rc;
+  DeviceGuard g(h->device);
   return h->spmv_local(y, x, send, (hipStream_t)stream);
 }
 int cfs_hip_sym_spmv_phases_async(cfs_hip_sym_t h, void *y, const void *x, void *send,
                                   int phases, void *stream) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  int rc = check_placement(h, y, x);
+  if (rc) return rc;
+  DeviceGuard g(h->device);
   return h->spmv_local(y, x, send, (hipStream_t)stream, phases);
 }
 int cfs_hip_sym_recv_fold_async(cfs_hip_sym_t h, void *y, const void *recv, void *stream) {
   if (!h || !y) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  DeviceGuard g(h->device);
   return h->recv_fold(y, recv, (hipStream_t)stream);
 }
 
@@ -1320,6 +1461,12 @@ int cfs_hip_sym_debug_timeline(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
                                unsigned long long *stamps, int capacity_words, int *ngroups) {
   if (!h || !y_dev || !x_dev || !stamps || !ngroups) return set_err(CFS_HIP_ERR_ARG, "null argument");
   return h->timeline(y_dev, x_dev, stamps, capacity_words, ngroups);
+}
+
+int cfs_hip_sym_debug_group_features(cfs_hip_sym_t h, long long *out, int capacity_words,
+                                     int *ngroups) {
+  if (!h || !out || !ngroups) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  return h->group_features(out, capacity_words, ngroups);
 }
 
 int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out) {
@@ -1342,7 +1489,7 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   SymPlan<V> P;
   if (!cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
                                nranks > 1 ? row_splits : nullptr, to_opts(opt), P))
-    return set_err(CFS_HIP_ERR_UNSUPPORTED, P.error);
+    return set_err(plan_error_code(P.error), P.error);
   std::vector<int32_t> r, c;
   std::vector<V> v;
   cfs_plan::decode_plan(P, r, c, v);
@@ -1484,7 +1631,7 @@ int cfs_hip_sym_plan_send_info_f64(int n, const int *rowptr, const int *colind,
   SymPlan<double> P;
   if (!cfs_plan::build_plan<double>(n, rowptr, colind, values, nranks, rank, row_splits,
                                     to_opts(opt), P))
-    return set_err(CFS_HIP_ERR_UNSUPPORTED, P.error);
+    return set_err(plan_error_code(P.error), P.error);
   for (int r = 0; r < nranks; r++) send_counts[r] = P.send_counts[r];
   *nrows_out = (int)P.send_row.size();
   if (rows) {
@@ -1503,6 +1650,7 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
   if (rc) return rc;
   auto *m = new cfs_hip_csr_s();
   m->value_bytes = (int)sizeof(V);
+  HIPCHK(hipGetDevice(&m->device));
   m->nrows = nrows;
   m->ncols = ncols;
   m->nnz = rowptr[nrows];
@@ -1543,6 +1691,7 @@ int cfs_hip_csr_create_f32(int nrows, int ncols, const int *rowptr, const int *c
 int cfs_hip_csr_spmv_async(cfs_hip_csr_t h, void *y, const void *x, void *stream) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
   hipStream_t st = (hipStream_t)stream;
+  DeviceGuard g(h->device);
   if (h->nblocks > 0) {
     const int grid = h->nblocks < 256 * 8 ? h->nblocks : 256 * 8;
     if (h->value_bytes == 8)
@@ -1563,24 +1712,10 @@ int cfs_hip_csr_spmv_async(cfs_hip_csr_t h, void *y, const void *x, void *stream
 int cfs_hip_csr_spmv(cfs_hip_csr_t h, void *y, const void *x) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
   const size_t vb = (size_t)h->value_bytes;
-  const bool xd = is_device_ptr(x), yd = is_device_ptr(y);
-  const void *xdev = x;
-  void *ydev = y;
-  int rc;
-  if (!xd) {
-    if (!h->xstage.p && (rc = h->xstage.alloc((size_t)h->ncols * vb))) return rc;
-    HIPCHK(hipMemcpyAsync(h->xstage.p, x, (size_t)h->ncols * vb, hipMemcpyHostToDevice, g_stream));
-    xdev = h->xstage.p;
-  }
-  if (!yd) {
-    if (!h->ystage.p && (rc = h->ystage.alloc((size_t)h->nrows * vb))) return rc;
-    ydev = h->ystage.p;
-  }
-  if ((rc = cfs_hip_csr_spmv_async(h, ydev, xdev, g_stream))) return rc;
-  if (!yd)
-    HIPCHK(hipMemcpyAsync(y, ydev, (size_t)h->nrows * vb, hipMemcpyDeviceToHost, g_stream));
-  if (!xd || !yd) HIPCHK(hipStreamSynchronize(g_stream));
-  return 0;
+  return run_staged(h->device, h->stage, (size_t)h->ncols * vb, (size_t)h->nrows * vb, y, x,
+                    [&](void *yd, const void *xd, hipStream_t st) {
+                      return cfs_hip_csr_spmv_async(h, yd, xd, (void *)st);
+                    });
 }
 
 int cfs_hip_csr_destroy(cfs_hip_csr_t h) {

@@ -176,6 +176,8 @@ template <typename V> struct SymPlan {
   bool mirrored = false;    // shard built with mirror_offblock (no sends)
   int64_t mirror_entries = 0; // one-sided entries stored for rows of higher ranks
   int64_t onesided_slots = 0; // halo slots without a y window
+  std::vector<int32_t> tile_rounds; // [T] packet rounds of a tile: sum over its slices of the
+                                    // longest lane's packet count (issue cost, not bytes)
   std::string error;
 };
 
@@ -294,6 +296,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     if (l < e && colind[l] == i) return values[l];
     for (int q = b; q < e; q++)
       if (colind[q] == i) return values[q];
+#pragma omp atomic write
     mirror_fail = true; // structurally unsymmetric input
     return V(0);
   };
@@ -694,6 +697,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   }
   pt.lap("core: vrows + sizes");
   bool dup_error = false;
+  P.tile_rounds.assign(T, 0);
 #pragma omp parallel num_threads(host_threads())
   {
     std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
@@ -721,7 +725,10 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
         const bool oa = offblock(a), ob = offblock(b);
         return oa != ob ? ob : a < b;
       });
-      if ((int)hcols.size() != t.nslots - t.nown) dup_error = true;
+      if ((int)hcols.size() != t.nslots - t.nown) {
+#pragma omp atomic write
+        dup_error = true;
+      }
       {
         int ny = t.nown;
         for (int c : hcols)
@@ -764,6 +771,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
         }
         const SliceMeta &sm = P.slice_meta[t.slice_base + s];
         int64_t o = sm.voff, os = sm.soff_cnt0 & 0x1ffffff;
+        P.tile_rounds[ti] += amax;
         for (int g = 0; g < amax; g++) {
           int cnt = 0;
           while (cnt < m && vr[p0 + cnt].a > g) cnt++;
@@ -800,7 +808,10 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
             e++;
           }
         }
-        if (e != t.ncoo) dup_error = true;
+        if (e != t.ncoo) {
+#pragma omp atomic write
+          dup_error = true;
+        }
       }
       for (int c : hcols) colmap[c] = -1;
     }
@@ -1131,6 +1142,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
         if (c > i) {
           src = lower_value_pos(c, i);
           if (src < 0) {
+#pragma omp atomic write
             asym = true; // structurally unsymmetric input: keep the natural order
             src = j;
           }
@@ -1145,7 +1157,10 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
       for (size_t k = 0; k < tmp.size(); k++) {
         // duplicate entries (the reader keeps them) cannot be paired with their
         // mirror images one to one: such matrices keep their natural order
-        if (k > 0 && tmp[k].first == tmp[k - 1].first) asym = true;
+        if (k > 0 && tmp[k].first == tmp[k - 1].first) {
+#pragma omp atomic write
+          asym = true;
+        }
         bci[q] = tmp[k].first;
         bva[q] = tmp[k].second;
         q++;

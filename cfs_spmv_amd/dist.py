@@ -175,7 +175,7 @@ def build_shard(n, rowptr, colind, values, nranks, rank, row_splits, device, opt
     import torch
     import torch.distributed as dist
     from . import matrix as M
-    from ._lib import CfsHipError, Options
+    from ._lib import CfsHipError, ERR_MIRROR, Options
     flags = options.flags if options is not None else 0
     base = (options.max_slots, options.max_tile_nnz, options.block_threads) if options is not None \
         else (0, 0, 0)
@@ -187,7 +187,7 @@ def build_shard(n, rowptr, colind, values, nranks, rank, row_splits, device, opt
             A = M.SymMatrix(n, rowptr, colind, values, options=Options(*base, flags & ~M.FLAG_SHARD_EXCHANGE),
                             row_splits=row_splits, rank=rank)
         except CfsHipError as e:
-            if "mirror" not in str(e):
+            if e.code != ERR_MIRROR:
                 raise
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32,

@@ -35,8 +35,14 @@ extern "C" {
 #define CFS_HIP_OK 0
 #define CFS_HIP_ERR_ARG (-1)      /* bad argument                            */
 #define CFS_HIP_ERR_DEVICE (-2)   /* HIP runtime failure (message has detail) */
+/* the tile schedule does not cover this matrix (a row denser than an LDS window,
+ * offsets exhausted): the caller may fall back to the general CSR kernel.      */
 #define CFS_HIP_ERR_UNSUPPORTED (-3)
 #define CFS_HIP_ERR_NOMEM (-4)
+#define CFS_HIP_ERR_INTERNAL (-5) /* a consistency check of the schedule builder failed */
+/* a shard cannot be built in the mirrored form (off-block structure unsymmetric
+ * or duplicated): rebuild it with CFS_HIP_FLAG_SHARD_EXCHANGE                   */
+#define CFS_HIP_ERR_MIRROR (-6)
 
 typedef struct cfs_hip_sym_s *cfs_hip_sym_t; /* symmetric (SSS) matrix handle */
 typedef struct cfs_hip_csr_s *cfs_hip_csr_t; /* general CSR matrix handle     */
@@ -45,8 +51,14 @@ typedef struct cfs_hip_csr_s *cfs_hip_csr_t; /* general CSR matrix handle     */
 int cfs_hip_abi_version(void);
 const char *cfs_hip_last_error(void);
 int cfs_hip_device_count(int *count);
-/* Bind the calling process to `device` (one process per GPU).  Idempotent.   */
+/* Make `device` the calling thread's current device and the HOME of the
+ * synchronous entry points (cfs_hip_alloc, host-pointer SpMV).  Idempotent, and it
+ * leaves the contexts of other devices alone: handles remember the device they
+ * were created on and keep working.  A process that never calls it adopts the
+ * device that is current in the calling thread at the first use (never a
+ * hard-wired device 0).                                                        */
 int cfs_hip_init(int device);
+int cfs_hip_current_device(int *device); /* the home device */
 /* stream used internally by the synchronous (host-pointer capable) entry
  * points; created by cfs_hip_init.  The *_async entry points take the caller's
  * hipStream_t verbatim: NULL there means HIP's null stream (which is what
@@ -60,6 +72,11 @@ int cfs_hip_synchronize(void *stream); /* NULL = the library stream */
 #define CFS_HIP_MEM_PINNED 1 /* hipHostMalloc: page-locked host staging buffer      */
 int cfs_hip_alloc(size_t bytes, int kind, void **out);
 int cfs_hip_free(void *p, int kind);
+/* The page-locked blocks come from a pool (power-of-two classes >= 64 KiB; a
+ * released block is kept for the next request).  owns: 1 if p is a live block of
+ * the pool (the allocator seam frees those through cfs_hip_free).              */
+int cfs_hip_pinned_owns(const void *p);
+int cfs_hip_pinned_pool_stats(size_t *live_blocks, size_t *spare_blocks, size_t *spare_bytes);
 #define CFS_HIP_H2D 0
 #define CFS_HIP_D2H 1
 #define CFS_HIP_D2D 2
@@ -219,6 +236,16 @@ int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out);
 int cfs_hip_sym_debug_timeline(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
                                unsigned long long *stamps, int capacity_words,
                                int *ngroups);
+
+/* developer diagnostic: what every persistent group (in group order; block b runs
+ * group (b % 8) * (ngroups / 8) + b / 8) has to do, CFS_HIP_GROUP_FEATURES words
+ * each: [0] tiles, [1] rows, [2] virtual rows, [3] slices, [4] packet rounds (sum
+ * over slices of the longest lane's packets), [5] value-stream entries, [6] slot-
+ * stream entries, [7] COO leftovers, [8] halo slots, [9] slots.  tools/ fit the
+ * cost model of the row cut against the timeline with it.                      */
+#define CFS_HIP_GROUP_FEATURES 10
+int cfs_hip_sym_debug_group_features(cfs_hip_sym_t h, long long *out, int capacity_words,
+                                     int *ngroups);
 
 /* ---- host-only self-check of the tile schedule (needs no GPU): builds the
  *      schedule tune() would upload, decodes it back to (row, col, value)

@@ -1,7 +1,11 @@
 // allocator.cpp -- internal_alloc / internal_free / internal_copy
-// (reference seam: src/allocator.cpp:8-43).  cpu = posix_memalign(64) as in the
-// reference; gpu = HBM through the C ABI.  Failures print and exit(1), like
-// the reference does.
+// (reference seam: src/allocator.cpp:8-43).  gpu = HBM through the C ABI.  cpu =
+// 64-byte aligned host memory as in the reference; vectors of 64 KiB .. 256 MiB
+// come from the page-locked pool of the runtime (CFS_HIP_MEM_PINNED) once a
+// device is bound, so that an unmodified caller that hands its host x / y to
+// SpDMV (test/test_spmv_mmf.cpp:82-83) is DMA-ed in place instead of being
+// copied through a staging block.  Failures print and exit(1), like the
+// reference does.
 #include "utils/allocator.hpp"
 
 #include <cstdlib>
@@ -14,6 +18,8 @@ namespace cfs {
 namespace util {
 namespace memory {
 
+static const size_t kPinnedMin = (size_t)64 << 10, kPinnedMax = (size_t)256 << 20;
+
 static void die(const char *what) {
   std::cout << "[ERROR]: " << what << ": " << cfs_hip_last_error() << std::endl;
   exit(1);
@@ -25,6 +31,12 @@ void *internal_alloc(size_t bytes, Platform platform) {
     if (cfs_hip_alloc(bytes, CFS_HIP_MEM_DEVICE, &pointer) != 0) die("cfs_hip_alloc() failed");
     return pointer;
   }
+  int dev = -1;
+  if (bytes >= kPinnedMin && bytes <= kPinnedMax && getenv("CFS_NO_PINNED") == nullptr &&
+      cfs_hip_device_count(&dev) == 0 && dev > 0 &&
+      cfs_hip_alloc(bytes, CFS_HIP_MEM_PINNED, &pointer) == 0)
+    return pointer;
+  pointer = nullptr;
   if (posix_memalign(&pointer, 64, bytes ? bytes : 64) != 0) {
     std::cout << "[ERROR]: posix_memalign() failed!" << std::endl;
     exit(1);
@@ -36,6 +48,10 @@ void internal_free(void *pointer, Platform platform) {
   if (!pointer) return;
   if (platform == Platform::gpu) {
     if (cfs_hip_free(pointer, CFS_HIP_MEM_DEVICE) != 0) die("cfs_hip_free() failed");
+    return;
+  }
+  if (cfs_hip_pinned_owns(pointer)) {
+    if (cfs_hip_free(pointer, CFS_HIP_MEM_PINNED) != 0) die("cfs_hip_free() failed");
     return;
   }
   free(pointer);

@@ -51,8 +51,30 @@ inline bool tok_is(const Tokens &t, int i, const char *s) {
   size_t l = strlen(s);
   return i < t.n && (size_t)(t.e[i] - t.b[i]) == l && memcmp(t.b[i], s, l) == 0;
 }
-// atoi on a token (the token is followed by a blank or '\n', so strtol stops)
-inline long tok_long(const Tokens &t, int i) { return strtol(t.b[i], nullptr, 10); }
+// atoi on a token, bounded by the token's end: the file is mmap'ed, and a last
+// token that runs to the end of a mapping whose size is a multiple of the page size
+// has nothing behind it for strtol to stop at.  Like atoi: optional sign, digits,
+// stops at the first other character.
+inline long tok_long(const Tokens &t, int i) {
+  const char *q = t.b[i], *e = t.e[i];
+  bool neg = false;
+  if (q < e && (*q == '-' || *q == '+')) neg = *q++ == '-';
+  long v = 0;
+  while (q < e && *q >= '0' && *q <= '9') v = v * 10 + (*q++ - '0');
+  return neg ? -v : v;
+}
+// strtod on a copy of the token (NUL-terminated: see tok_long)
+inline double tok_strtod(const char *b, const char *e) {
+  char buf[128];
+  const size_t l = (size_t)(e - b);
+  if (l < sizeof buf) {
+    memcpy(buf, b, l);
+    buf[l] = 0;
+    return strtod(buf, nullptr);
+  }
+  std::string tmp(b, e);
+  return strtod(tmp.c_str(), nullptr);
+}
 // atof on a token, bit-exact with strtod: Clinger's fast path -- at most 15
 // significant digits (mantissa < 2^53) and a decimal exponent within +-22 are ONE
 // correctly rounded multiplication / division of two exact doubles -- covers what
@@ -103,7 +125,7 @@ inline double tok_double(const Tokens &t, int i) {
     exp10 += eneg ? -ev : ev;
     q = r;
   }
-  if (!any || !ok || q != e || exp10 < -22 || exp10 > 22) return strtod(b, nullptr);
+  if (!any || !ok || q != e || exp10 < -22 || exp10 > 22) return tok_strtod(b, e);
   double v = (double)m; // exact: m < 10^15 < 2^53
   v = exp10 < 0 ? v / p10[-exp10] : v * p10[exp10];
   return neg ? -v : v;
@@ -372,6 +394,7 @@ static bool ParseMmfCsr(const std::string &filename, CsrArrays<IndexType, ValueT
       const Elem &el = part[i][k];
       if (el.row < 0 || el.row >= nrows || el.col < 0 || el.col >= ncols ||
           (symmetric && el.row != el.col && (el.col >= nrows || el.row >= ncols))) {
+#pragma omp atomic write
         range_error = true;
         continue;
       }

@@ -73,8 +73,34 @@ def _worker(rank, world, port, name, scale, q, exchange="all_to_all"):
         x = synth.make_x(n)
         rs = cfs.balanced_splits(n, rp, ci, world)
         be = HostShardDouble(n, rp, ci, va, world, rank, rs)
-        sh = ShardedSym(be, world, rank, np.float64, torch.device("cpu"), exchange=exchange,
-                        row_splits=rs)
+        rccl_branch = exchange == "reduce_scatter_rccl_branch"
+        sh = ShardedSym(be, world, rank, np.float64, torch.device("cpu"),
+                        exchange="reduce_scatter" if rccl_branch else exchange, row_splits=rs)
+        calls = []
+        if rccl_branch:
+            # drive the NON-gloo branch of _finish_reduce_scatter (the one RCCL takes on
+            # the GPU box): the process group claims to be "nccl" and
+            # reduce_scatter_tensor(async_op=True) is served by a stand-in with the same
+            # contract (sum over ranks, rank r receives block r, returns a Work)
+            class Work:
+                def wait(self):
+                    calls.append("wait")
+
+            class DistShim:
+                def __getattr__(self, k):
+                    return getattr(dist, k)
+
+                def get_backend(self, pg=None):
+                    return "nccl"
+
+                def reduce_scatter_tensor(self, out, inp, group=None, async_op=False):
+                    assert async_op and inp.numel() == out.numel() * world
+                    tmp = inp.clone()
+                    dist.all_reduce(tmp, group=group)
+                    out.copy_(tmp[rank * out.numel():(rank + 1) * out.numel()])
+                    calls.append("reduce_scatter_tensor")
+                    return Work()
+            sh.dist = DistShim()
         xt = torch.from_numpy(x.copy())
         yb = torch.full((be.row_end - be.row_begin,), 7.0, dtype=torch.float64)
         for _ in range(2):  # twice: buffers are reused
@@ -92,6 +118,8 @@ def _worker(rank, world, port, name, scale, q, exchange="all_to_all"):
         # what this rank received must be exactly the rows the others aimed at it
         ok_rows = bool(np.all((be.recv_rows >= be.row_begin) & (be.recv_rows < be.row_end))) \
             if be.recv_rows is not None and be.recv_rows.size else True
+        if rccl_branch:  # the branch really ran: one collective + one wait per SpMV
+            assert calls == ["reduce_scatter_tensor", "wait"] * 2, calls
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, err, ok_rows, int(sh.nsend), int(sh.nrecv)))
@@ -102,7 +130,8 @@ def _worker(rank, world, port, name, scale, q, exchange="all_to_all"):
 
 @pytest.mark.parametrize("world,name,scale,exchange", [
     (2, "Flan_1565", 0.01, "all_to_all"), (3, "pwtk", 0.03, "all_to_all"),
-    (2, "ldoor", 0.01, "all_to_all"), (3, "Flan_1565", 0.01, "reduce_scatter")])
+    (2, "ldoor", 0.01, "all_to_all"), (3, "Flan_1565", 0.01, "reduce_scatter"),
+    (2, "Flan_1565", 0.01, "reduce_scatter_rccl_branch")])
 def test_sharded_exchange_gloo(world, name, scale, exchange):
     import torch.multiprocessing as mp
     s = socket.socket()

@@ -51,6 +51,17 @@ def test_parallel_reader_is_clean_under_asan_ubsan(tmp_path):
         "neg.mtx": "%%MatrixMarket matrix coordinate real general\n-3 3 2\n1 1 1.0\n",
         "huge.mtx": "%%MatrixMarket matrix coordinate real general\n2147483647 2147483647 3\n1 1 1.0\n",
     }
+    # a file whose size is an exact multiple of the page size and whose last token runs
+    # to the end of the mapping (no trailing newline): an integer token (pattern entry)
+    # and a 20-digit value that takes the strtod path
+    def page_file(last_line):
+        head = "%%MatrixMarket matrix coordinate real general\n"
+        body = "9 9 3\n1 1 1.0\n2 2 2.0\n" + last_line
+        pad = 4096 - (len(head) + len(body)) - 2
+        return head + "%" + "p" * pad + "\n" + body
+    bad["page_int.mtx"] = page_file("9 8")
+    bad["page_dbl.mtx"] = page_file("9 8 1.2345678901234567890")
+    assert len(bad["page_int.mtx"]) == 4096 and len(bad["page_dbl.mtx"]) == 4096
     for name, text in bad.items():
         (tmp_path / name).write_text(text)
         files.append(str(tmp_path / name))
