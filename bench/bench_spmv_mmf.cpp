@@ -55,6 +55,8 @@ int main(int argc, char **argv) {
   }
   const size_t loops = (size_t)atoi(argv[3]);
   const int nthreads = (int)get_num_threads();
+  // CFS_NUM_GPUS shards a symmetric (SSS / HYB) matrix; the general CSR kernel runs on one
+  const int ngpus = fmt == 0 ? 1 : get_num_gpus();
   static const Format formats[] = {Format::csr, Format::sss, Format::hyb};
   static const char *names[] = {"CSR", "SSS", "HYB"};
 
@@ -104,7 +106,7 @@ int main(int argc, char **argv) {
        << " preproc(sec): " << preproc_time << " t(sec): " << compute_time / loops
        << " gflops/s: " << gflops << " threads: " << nthreads
        << " size(MB): " << A->size() / (float)(1024 * 1024) << " gbytes/s: " << gbs
-       << " hbm_pct: " << 100.0 * gbs / 8000.0 << " gpus: 1" << endl;
+       << " hbm_pct: " << 100.0 * gbs / (8000.0 * ngpus) << " gpus: " << ngpus << endl;
   free(path);
 
   delete A;

@@ -27,7 +27,8 @@ class SymStats(C.Structure):
                 ("halo_slots", C.c_int64), ("fold_rows", C.c_int64),
                 ("remote_vals", C.c_int64), ("lds_bytes", C.c_int64),
                 ("bytes_algorithmic", C.c_int64), ("bytes_streamed", C.c_int64),
-                ("device_bytes", C.c_int64), ("mirror_entries", C.c_int64)]
+                ("device_bytes", C.c_int64), ("mirror_entries", C.c_int64),
+                ("far_entries", C.c_int64), ("ngroups", C.c_int), ("reserved_", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -38,7 +39,7 @@ class PlanReport(C.Structure):
                 ("nslices", C.c_int64), ("halo_slots", C.c_int64), ("stream_len", C.c_int64),
                 ("nnz_low", C.c_int64), ("fold_rows", C.c_int64), ("remote_vals", C.c_int64),
                 ("decoded", C.c_int64), ("mismatches", C.c_int64),
-                ("mirror_entries", C.c_int64)]
+                ("mirror_entries", C.c_int64), ("far_entries", C.c_int64)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -50,7 +51,7 @@ SYMBOLS = [
     "cfs_hip_current_device", "cfs_hip_pinned_owns", "cfs_hip_pinned_pool_stats", "cfs_hip_default_stream", "cfs_hip_synchronize", "cfs_hip_alloc", "cfs_hip_free",
     "cfs_hip_memcpy", "cfs_hip_memset", "cfs_hip_sym_create_f64", "cfs_hip_sym_create_f32",
     "cfs_hip_sym_create_shard_f64", "cfs_hip_sym_create_shard_f32",
-    "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_spmv",
+    "cfs_hip_sym_create_multi_f64", "cfs_hip_sym_create_multi_f32", "cfs_hip_sym_num_gpus", "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_spmv",
     "cfs_hip_sym_spmv_async", "cfs_hip_sym_shard_send_counts", "cfs_hip_sym_shard_send_rows",
     "cfs_hip_sym_shard_set_recv", "cfs_hip_sym_spmv_local_async",
     "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_debug_group_features", "cfs_hip_sym_plan_check_f64",
@@ -95,6 +96,8 @@ def load():
             C.c_int, vp, vp, vp, C.POINTER(Options), C.POINTER(vp)]
         getattr(lib, "cfs_hip_sym_create_shard_" + suf).argtypes = [
             C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(Options), C.POINTER(vp)]
+        getattr(lib, "cfs_hip_sym_create_multi_" + suf).argtypes = [
+            C.c_int, vp, vp, vp, C.c_int, vp, C.POINTER(Options), C.POINTER(vp)]
         getattr(lib, "cfs_hip_sym_plan_check_" + suf).argtypes = [
             C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(Options),
             C.POINTER(PlanReport)]
@@ -103,6 +106,7 @@ def load():
     lib.cfs_hip_sym_plan_send_info_f64.argtypes = [
         C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(Options), vp, vp, C.c_int, ip]
     lib.cfs_hip_sym_balanced_splits.argtypes = [C.c_int, vp, vp, C.c_int, vp]
+    lib.cfs_hip_sym_num_gpus.argtypes = [vp, ip]
     lib.cfs_hip_sym_destroy.argtypes = [vp]
     lib.cfs_hip_sym_spmv.argtypes = [vp, vp, vp]
     lib.cfs_hip_sym_spmv_async.argtypes = [vp, vp, vp, vp]

@@ -65,6 +65,9 @@ template <typename V> struct SymDev {
   const V *cvals; // COO leftovers (len % 4 per row): value, row slot, column slot
   const uint16_t *crows;
   const uint16_t *ccols;
+  const V *fvals; // FAR sections (HYB): value, own row slot, global column
+  const uint16_t *frows;
+  const int32_t *fcols;
   V *strip;
   int row_begin;
   int lds_slots;
@@ -148,31 +151,78 @@ __device__ __forceinline__ uint32_t slot_block(unsigned long long leaders, int c
 // OFFB (a mirrored shard, cfs_plan::Options::mirror_offblock): slots >= ny are
 // off-block columns; their entries are one-sided -- row side only, the rank that
 // owns the column computes the transposed side from its own copy of the entry.
-template <typename V, int MODE, bool OFFB>
-__device__ __forceinline__ void lds_update(const V *xl, double *yl, V a, unsigned c, V xi, V &acc,
-                                           unsigned ny) {
+// The y window of a tile.  Default: one fp64 word per slot, ds_add_f64 -- the order in
+// which the waves' updates of a slot arrive varies from run to run, and so do the last
+// bits of y.  DETERMINISTIC (CFS_HIP_FLAG_DETERMINISTIC): every contribution p is
+// turned into a fixed-point number of 2 x 40 bits below a per-tile scale 2^e and added
+// with INTEGER atomics (hi and lo word of the slot): integer addition is associative,
+// so the sums -- and y -- are bit-identical whatever the order.  The scale covers the
+// largest possible row sum of the tile (e = exponent of max|a| + exponent of max|x| in
+// the window + 12 + 16 bits of head-room in the words themselves); a contribution
+// keeps 2^-68 of the largest product of its tile, i.e. full fp64 precision for rows
+// down to 2^-15 of it.
+template <bool DET> struct YWin {
+  double *y;         // !DET: fp64 sums.  DET: the hi words (as long long)
+  long long *lo;     // DET: the lo words
+  double inv;        // DET: 2^(40 - e)
+  __device__ __forceinline__ void add(unsigned slot, double p) const {
+    if (!DET) {
+      atomicAdd(&y[slot], p);
+    } else {
+      const double q = p * inv; // exact: inv is a power of two
+      const double h = trunc(q);
+      const long long hi = (long long)h;
+      const long long l2 = (long long)rint((q - h) * 0x1p40); // q - h is exact
+      atomicAdd(reinterpret_cast<unsigned long long *>(y) + slot, (unsigned long long)hi);
+      atomicAdd(reinterpret_cast<unsigned long long *>(lo) + slot, (unsigned long long)l2);
+    }
+  }
+  __device__ __forceinline__ void zero(unsigned slot) const {
+    if (!DET) {
+      y[slot] = 0.0;
+    } else {
+      reinterpret_cast<long long *>(y)[slot] = 0;
+      lo[slot] = 0;
+    }
+  }
+  // value of a slot; unscale = 2^(e - 40)
+  __device__ __forceinline__ double get(unsigned slot, double unscale) const {
+    if (!DET) return y[slot];
+    const long long hi = reinterpret_cast<const long long *>(y)[slot];
+    return ((double)hi + (double)lo[slot] * 0x1p-40) * unscale;
+  }
+};
+// 2^k as a double, k clamped to the normal range
+__device__ __forceinline__ double pow2_double(int k) {
+  k = max(-1000, min(1000, k));
+  return __longlong_as_double((long long)(k + 1023) << 52);
+}
+
+template <typename V, int MODE, bool OFFB, bool DET>
+__device__ __forceinline__ void lds_update(const V *xl, const YWin<DET> &yw, V a, unsigned c, V xi,
+                                           V &acc, unsigned ny) {
   if (MODE == 2) {
     acc = fma(a, xi + V(c), acc);
   } else {
     acc = fma(a, xl[c], acc);
-    if (MODE == 0 && (!OFFB || c < ny)) atomicAdd(&yl[c], (double)a * (double)xi);
+    if (MODE == 0 && (!OFFB || c < ny)) yw.add(c, (double)a * (double)xi);
   }
 }
-template <typename V, int MODE, bool OFFB>
-__device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, double *yl, V xi,
-                                               V &acc, unsigned ny) {
-  lds_update<V, MODE, OFFB>(xl, yl, p.v[0], p.c.x, xi, acc, ny);
-  lds_update<V, MODE, OFFB>(xl, yl, p.v[1], p.c.y, xi, acc, ny);
-  lds_update<V, MODE, OFFB>(xl, yl, p.v[2], p.c.z, xi, acc, ny);
-  lds_update<V, MODE, OFFB>(xl, yl, p.v[3], p.c.w, xi, acc, ny);
+template <typename V, int MODE, bool OFFB, bool DET>
+__device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, const YWin<DET> &yl,
+                                               V xi, V &acc, unsigned ny) {
+  lds_update<V, MODE, OFFB, DET>(xl, yl, p.v[0], p.c.x, xi, acc, ny);
+  lds_update<V, MODE, OFFB, DET>(xl, yl, p.v[1], p.c.y, xi, acc, ny);
+  lds_update<V, MODE, OFFB, DET>(xl, yl, p.v[2], p.c.z, xi, acc, ny);
+  lds_update<V, MODE, OFFB, DET>(xl, yl, p.v[3], p.c.w, xi, acc, ny);
 }
 // one COO leftover a = A[row(r)][col(c)]: both sides through LDS atomics
-template <typename V, int MODE, bool OFFB>
-__device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigned r, unsigned c,
-                                           unsigned ny) {
+template <typename V, int MODE, bool OFFB, bool DET>
+__device__ __forceinline__ void coo_update(const V *xl, const YWin<DET> &yl, V a, unsigned r,
+                                           unsigned c, unsigned ny) {
   if (MODE == 0 || MODE == 1) {
-    atomicAdd(&yl[r], (double)a * (double)xl[c]);
-    if (MODE == 0 && (!OFFB || c < ny)) atomicAdd(&yl[c], (double)a * (double)xl[r]);
+    yl.add(r, (double)a * (double)xl[c]);
+    if (MODE == 0 && (!OFFB || c < ny)) yl.add(c, (double)a * (double)xl[r]);
   }
 }
 
@@ -194,8 +244,11 @@ __device__ __forceinline__ void coo_update(const V *xl, double *yl, V a, unsigne
 // as a result path): 1 = no transposed LDS atomics, 2 = no LDS traffic at all,
 // 3 = windows only (no matrix stream), 4 = matrix stream only (no windows).
 // ---------------------------------------------------------------------------
-template <typename V, int BLOCK, int MODE, bool NT, bool OFFB, int U>
-__global__ void __launch_bounds__(BLOCK)
+// (second launch bound: 4 waves per SIMD must stay resident -- two 512-thread
+// workgroups, or one of 1 024, per CU -- i.e. at most 128 VGPRs; the persistent grid
+// is sized for exactly that residency)
+template <typename V, int BLOCK, int MODE, bool NT, bool OFFB, int U, bool DET = false>
+__global__ void __launch_bounds__(BLOCK, 4)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const Tile *__restrict__ a_gfirst,
                         const int32_t *__restrict__ a_group_ptr,
                         const int32_t *__restrict__ a_slot_col,
@@ -204,8 +257,9 @@ __global__ void __launch_bounds__(BLOCK)
                         const uint8_t *__restrict__ a_leadlane, const V *__restrict__ a_vals,
                         const uint16_t *__restrict__ a_slots, const V *__restrict__ a_cvals,
                         const uint16_t *__restrict__ a_crows,
-                        const uint16_t *__restrict__ a_ccols, V *__restrict__ a_strip,
-                        const int a_row_begin, const int a_lds_slots,
+                        const uint16_t *__restrict__ a_ccols, const V *__restrict__ a_fvals,
+                        const uint16_t *__restrict__ a_frows, const int32_t *__restrict__ a_fcols,
+                        V *__restrict__ a_strip, const int a_row_begin, const int a_lds_slots,
                         const V *__restrict__ x, V *__restrict__ y,
                         unsigned long long *__restrict__ dbg) {
   // every array is a separate __restrict__ argument: read-only metadata at
@@ -225,16 +279,28 @@ __global__ void __launch_bounds__(BLOCK)
     const V *__restrict__ cvals;
     const uint16_t *__restrict__ crows;
     const uint16_t *__restrict__ ccols;
+    const V *__restrict__ fvals;
+    const uint16_t *__restrict__ frows;
+    const int32_t *__restrict__ fcols;
     V *__restrict__ strip;
     int row_begin, lds_slots;
   } d = {a_tiles, a_gfirst, a_group_ptr, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_leadlane, a_vals,
-         a_slots, a_cvals, a_crows, a_ccols, a_strip, a_row_begin, a_lds_slots};
+         a_slots, a_cvals, a_crows, a_ccols, a_fvals, a_frows, a_fcols, a_strip, a_row_begin, a_lds_slots};
   // slice ticket counter of the current tile (16 B so the dynamic region below
   // stays 16-byte aligned)
   __shared__ __align__(16) int cfs_ticket[4];
   extern __shared__ __align__(16) unsigned char cfs_smem[];
-  double *yl = reinterpret_cast<double *>(cfs_smem); // fp64 first: keeps 8-B alignment
-  V *xl = reinterpret_cast<V *>(yl + d.lds_slots);
+  // y window first (8-byte words: one per slot, two in the deterministic build), then x
+  YWin<DET> yl;
+  yl.y = reinterpret_cast<double *>(cfs_smem);
+  yl.lo = reinterpret_cast<long long *>(cfs_smem) + (DET ? d.lds_slots : 0);
+  yl.inv = 1.0;
+  V *xl = reinterpret_cast<V *>(yl.y + (DET ? 2 : 1) * d.lds_slots);
+  if (DET) { // exponent of max |x| in the window: two words, tiles alternate
+    if (threadIdx.x == 0) cfs_ticket[2] = cfs_ticket[3] = 0;
+    __syncthreads();
+  }
+  int det_parity = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   // wave-uniform by construction: keep it in an SGPR so that slice bookkeeping is
   // scalar (s_load / s_cbranch) and never waits on the vector-memory counter
@@ -319,8 +385,20 @@ __global__ void __launch_bounds__(BLOCK)
       const int i = tid + k * BLOCK;
       if (i < nslots) {
         xl[i] = xr[k];
-        yl[i] = 0.0;
+        yl.zero(i);
       }
+    }
+    if (DET) { // biased exponent field of the largest |x| this thread brought in
+      int ex = 0;
+#pragma unroll
+      for (int k = 0; k < U; ++k)
+        if (tid + k * BLOCK < nslots) {
+          const double ax = fabs((double)xr[k]);
+          ex = max(ex, (int)((unsigned long long)__double_as_longlong(ax) >> 52));
+        }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ex = max(ex, __shfl_xor(ex, o));
+      if (lane == 0) atomicMax(&cfs_ticket[2 + det_parity], ex);
     }
     // the matrix stream does not depend on x: this wave's first slice header and
     // head packet (and its first COO packet) are requested BEFORE the barrier --
@@ -365,6 +443,15 @@ __global__ void __launch_bounds__(BLOCK)
     }
     if (tid == 0) cfs_ticket[0] = 2 * NW;
     __syncthreads();
+    double det_unscale = 1.0;
+    if (DET) {
+      // |a| < 2^aexp (plan), |x| < 2^(E - 1022) (window), 12 bits for the longest row sum
+      const int e = t.aexp + (__builtin_amdgcn_readfirstlane(cfs_ticket[2 + det_parity]) - 1022) + 12;
+      yl.inv = pow2_double(40 - e);
+      det_unscale = pow2_double(e - 40);
+      det_parity ^= 1;
+      if (tid == 0) cfs_ticket[2 + det_parity] = 0; // the next tile's word (see the header comment)
+    }
     if (dbg && tid == 0 && ti == t0) dbg[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
 
     while (MODE != 3 && s < nsl) {
@@ -411,11 +498,11 @@ __global__ void __launch_bounds__(BLOCK)
         const int cnt1 = __popcll(__ballot(a > g + 1));
         const uint32_t off1 = off + 4u * (uint32_t)cnt, soff1 = soff + slot_block(leaders, cnt);
         fetch_packet<NT>(B, tv, ts, off1, soff1, cnt1, leaders, lane, lr);
-        if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
+        if (a > g) consume_packet<V, MODE, OFFB, DET>(A, xl, yl, xi, acc, ny);
         const int cnt2 = __popcll(__ballot(a > g + 2));
         const uint32_t off2 = off1 + 4u * (uint32_t)cnt1, soff2 = soff1 + slot_block(leaders, cnt1);
         fetch_packet<NT>(A, tv, ts, off2, soff2, cnt2, leaders, lane, lr);
-        if (a > g + 1) consume_packet<V, MODE, OFFB>(B, xl, yl, xi, acc, ny);
+        if (a > g + 1) consume_packet<V, MODE, OFFB, DET>(B, xl, yl, xi, acc, ny);
         g += 2;
         off = off2;
         soff = soff2;
@@ -425,12 +512,12 @@ __global__ void __launch_bounds__(BLOCK)
         const int cnt1 = __popcll(__ballot(a > g + 1));
         fetch_packet<NT>(B, tv, ts, off + 4u * (uint32_t)cnt, soff + slot_block(leaders, cnt), cnt1,
                          leaders, lane, lr);
-        if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
-        if (a > g + 1) consume_packet<V, MODE, OFFB>(B, xl, yl, xi, acc, ny);
+        if (a > g) consume_packet<V, MODE, OFFB, DET>(A, xl, yl, xi, acc, ny);
+        if (a > g + 1) consume_packet<V, MODE, OFFB, DET>(B, xl, yl, xi, acc, ny);
       } else if (amax - g == 1) {
-        if (a > g) consume_packet<V, MODE, OFFB>(A, xl, yl, xi, acc, ny);
+        if (a > g) consume_packet<V, MODE, OFFB, DET>(A, xl, yl, xi, acc, ny);
       }
-      if (s_cur * 64 + lane < nvr) atomicAdd(&yl[r], (double)fma(dg, xi, acc));
+      if (s_cur * 64 + lane < nvr) yl.add(r, (double)fma(dg, xi, acc));
     }
     // COO leftovers: packet p = wave, wave + NW, ...; the first one was requested
     // at the top of the tile
@@ -444,10 +531,35 @@ __global__ void __launch_bounds__(BLOCK)
         Cr = make_ushort4(rr.x, rr.y, rr.z, rr.w);
       }
       const int e0 = cp * 256 + lane * 4;
-      if (e0 + 0 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[0], Qr.x, Q.c.x, ny);
-      if (e0 + 1 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[1], Qr.y, Q.c.y, ny);
-      if (e0 + 2 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[2], Qr.z, Q.c.z, ny);
-      if (e0 + 3 < t.ncoo) coo_update<V, MODE, OFFB>(xl, yl, Q.v[3], Qr.w, Q.c.w, ny);
+      if (e0 + 0 < t.ncoo) coo_update<V, MODE, OFFB, DET>(xl, yl, Q.v[0], Qr.x, Q.c.x, ny);
+      if (e0 + 1 < t.ncoo) coo_update<V, MODE, OFFB, DET>(xl, yl, Q.v[1], Qr.y, Q.c.y, ny);
+      if (e0 + 2 < t.ncoo) coo_update<V, MODE, OFFB, DET>(xl, yl, Q.v[2], Qr.z, Q.c.z, ny);
+      if (e0 + 3 < t.ncoo) coo_update<V, MODE, OFFB, DET>(xl, yl, Q.v[3], Qr.w, Q.c.w, ny);
+    }
+    // FAR entries (HYB): a = A[row(r)][col] with col outside this tile and used only
+    // once by it -- or the mirror image of such an entry of another tile.  One-sided:
+    // y_l[r] += a * x[col], x gathered from global memory (L2): no slot, no strip
+    for (int fp = wave; MODE != 3 && fp < ((t.nfar + 255) >> 8); fp += NW) {
+      const size_t base = (size_t)t.far_off + (size_t)fp * 256u;
+      V fv[4];
+      if (sizeof(V) == 8) {
+        const cfs_d2 lo = *reinterpret_cast<const cfs_d2 *>(d.fvals + base + lane * 2);
+        const cfs_d2 hi = *reinterpret_cast<const cfs_d2 *>(d.fvals + base + 128 + lane * 2);
+        fv[0] = lo.x; fv[1] = lo.y; fv[2] = hi.x; fv[3] = hi.y;
+      } else {
+        const cfs_f4 q4 = *reinterpret_cast<const cfs_f4 *>(d.fvals + base + lane * 4);
+        fv[0] = q4.x; fv[1] = q4.y; fv[2] = q4.z; fv[3] = q4.w;
+      }
+      const cfs_us4 rr = *reinterpret_cast<const cfs_us4 *>(d.frows + base + lane * 4);
+      const int4 cc = *reinterpret_cast<const int4 *>(d.fcols + base + lane * 4);
+      const V x0 = x[cc.x], x1 = x[cc.y], x2 = x[cc.z], x3 = x[cc.w]; // padding: column 0
+      const int e0 = fp * 256 + lane * 4;
+      // (a deterministic build has no far entries: x[col] lies outside the window
+      // whose largest |x| sets the fixed-point scale)
+      if (e0 + 0 < t.nfar) yl.add(rr.x, (double)fv[0] * (double)x0);
+      if (e0 + 1 < t.nfar) yl.add(rr.y, (double)fv[1] * (double)x1);
+      if (e0 + 2 < t.nfar) yl.add(rr.z, (double)fv[2] * (double)x2);
+      if (e0 + 3 < t.nfar) yl.add(rr.w, (double)fv[3] * (double)x3);
     }
     if (dbg && lane == 0 && wave == 0 && ti + 1 == t1) dbg[blockIdx.x * 8 + 7] = __builtin_amdgcn_s_memrealtime();
     if (ti + 1 < t1) gather_x(d.tiles[ti + 1]); // lands behind the barrier + flush
@@ -465,8 +577,8 @@ __global__ void __launch_bounds__(BLOCK)
 #pragma unroll
       for (int k = 0; k < U; ++k) {
         const int i = tid + k * BLOCK;
-        if (i < nown) y[yidx[k]] = (V)yl[i];
-        else if (i < (int)ny) d.strip[t.halo_off + (i - nown)] = (V)yl[i];
+        if (i < nown) y[yidx[k]] = (V)yl.get(i, det_unscale);
+        else if (i < (int)ny) d.strip[t.halo_off + (i - nown)] = (V)yl.get(i, det_unscale);
       }
     }
   }
@@ -747,7 +859,7 @@ struct cfs_hip_sym_s {
 template <typename V> struct SymMatrix : cfs_hip_sym_s {
   SymPlan<V> P; // big arrays released after upload
   DevBuf tiles, gfirst, group_ptr, slot_col, rowinfo, diag, slice_meta, leadlane, vals, slots, strip;
-  DevBuf cvals, crows, ccols;
+  DevBuf cvals, crows, ccols, fvals, frows, fcols;
   DevBuf fold_rec, fold_idx, send_ptr, send_idx;
   DevBuf rfold_rec, rfold_idx;
   SymDev<V> dev{};
@@ -758,7 +870,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int64_t mirror_entries = 0;
   unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
   size_t lds_bytes = 0;
-  int64_t halo_slots = 0, stream_len = 0, slot_len = 0, nslices = 0, coo_len = 0;
+  int64_t halo_slots = 0, stream_len = 0, slot_len = 0, nslices = 0, coo_len = 0, far_len = 0, far_entries = 0;
 
   int upload() {
     int rc;
@@ -777,6 +889,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(ccols, P.ccols)
     UP(vals, P.vals)
     UP(slots, P.slots)
+    UP(fvals, P.fvals)
+    UP(frows, P.frows)
+    UP(fcols, P.fcols)
     {
       std::vector<int4> rec;
       std::vector<int32_t> rest;
@@ -795,6 +910,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     slot_len = P.slot_len;
     nslices = (int64_t)P.slice_meta.size();
     coo_len = P.coo_len;
+    far_len = P.far_len;
+    far_entries = P.far_entries;
     nfold = (int)P.fold_dst.size();
     nsend = (int)P.send_row.size();
     dev.tiles = (const Tile *)tiles.p;
@@ -810,10 +927,13 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     dev.ccols = (const uint16_t *)ccols.p;
     dev.vals = (const V *)vals.p;
     dev.slots = (const uint16_t *)slots.p;
+    dev.fvals = (const V *)fvals.p;
+    dev.frows = (const uint16_t *)frows.p;
+    dev.fcols = (const int32_t *)fcols.p;
     dev.strip = (V *)strip.p;
     dev.row_begin = P.row_begin;
     dev.lds_slots = P.lds_slots;
-    lds_bytes = (size_t)P.lds_slots * (sizeof(V) + sizeof(double));
+    lds_bytes = (size_t)P.lds_slots * (sizeof(V) + (P.deterministic ? 16 : 8));
     // the stream is cacheable across SpMVs only if it fits the 256 MiB Infinity Cache
     nt_stream = (stream_len * (int64_t)sizeof(V) + slot_len * 2) > (int64_t)240 * 1024 * 1024;
     // release the big host arrays; keep the small metadata
@@ -823,6 +943,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     std::vector<V>().swap(P.cvals);
     std::vector<uint16_t>().swap(P.crows);
     std::vector<uint16_t>().swap(P.ccols);
+    std::vector<V>().swap(P.fvals);
+    std::vector<uint16_t>().swap(P.frows);
+    std::vector<int32_t>().swap(P.fcols);
     std::vector<V>().swap(P.diag);
     std::vector<uint32_t>().swap(P.rowinfo);
     std::vector<int32_t>().swap(P.fold_idx);
@@ -831,8 +954,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   }
 
   // the instantiation of the tile kernel this handle launches
-  template <int BLOCK> static const void *pick_kernel(int mode, bool nt, bool offb, int u) {
+  template <int BLOCK> static const void *pick_kernel(int mode, bool nt, bool offb, int u, bool det) {
 #define CFS_K(M, N, O, UU) ((const void *)cfs_sym_tile_kernel<V, BLOCK, M, N, O, UU>)
+#define CFS_KDET(N, O, UU) ((const void *)cfs_sym_tile_kernel<V, 512, 0, N, O, UU, true>)
     constexpr int UM = cfs_plan::kSlotsPerThread;
     switch (mode) {
     case 1: return CFS_K(1, true, false, UM);
@@ -841,20 +965,30 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     case 4: return CFS_K(4, true, false, UM);
     default: break;
     }
+    if (det) { // CFS_HIP_FLAG_DETERMINISTIC: 512 threads only (to_opts)
+      static const void *const dtab[2][2][3] = {
+          {{CFS_KDET(false, false, 3), CFS_KDET(false, false, 6), CFS_KDET(false, false, UM)},
+           {CFS_KDET(false, true, 3), CFS_KDET(false, true, 6), CFS_KDET(false, true, UM)}},
+          {{CFS_KDET(true, false, 3), CFS_KDET(true, false, 6), CFS_KDET(true, false, UM)},
+           {CFS_KDET(true, true, 3), CFS_KDET(true, true, 6), CFS_KDET(true, true, UM)}}};
+      return dtab[nt ? 1 : 0][offb ? 1 : 0][u <= 3 ? 0 : (u <= 6 ? 1 : 2)];
+    }
     static const void *const tab[2][2][3] = {
         {{CFS_K(0, false, false, 3), CFS_K(0, false, false, 6), CFS_K(0, false, false, UM)},
          {CFS_K(0, false, true, 3), CFS_K(0, false, true, 6), CFS_K(0, false, true, UM)}},
         {{CFS_K(0, true, false, 3), CFS_K(0, true, false, 6), CFS_K(0, true, false, UM)},
          {CFS_K(0, true, true, 3), CFS_K(0, true, true, 6), CFS_K(0, true, true, UM)}}};
 #undef CFS_K
+#undef CFS_KDET
     return tab[nt ? 1 : 0][offb ? 1 : 0][u <= 3 ? 0 : (u <= 6 ? 1 : 2)];
   }
   const void *tile_kernel() {
     const int u = (P.lds_slots + P.block_threads - 1) / P.block_threads;
     switch (P.block_threads) {
-    case 256: return pick_kernel<256>(ablate_mode, nt_stream, offblock, u);
-    case 512: return pick_kernel<512>(ablate_mode, nt_stream, offblock, u);
-    default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u);
+    case 256: return pick_kernel<256>(ablate_mode, nt_stream, offblock, u, false);
+    case 512: return pick_kernel<512>(P.deterministic ? 0 : ablate_mode, nt_stream, offblock, u,
+                                      P.deterministic);
+    default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u, false);
     }
   }
   int launch_tiles(V *y, const V *x, hipStream_t st) {
@@ -866,6 +1000,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
                     (void *)&dev.slice_meta, (void *)&dev.leadlane, (void *)&dev.vals,
                     (void *)&dev.slots,
                     (void *)&dev.cvals, (void *)&dev.crows, (void *)&dev.ccols,
+                    (void *)&dev.fvals, (void *)&dev.frows, (void *)&dev.fcols,
                     (void *)&dev.strip, (void *)&dev.row_begin, (void *)&dev.lds_slots,
                     (void *)&x, (void *)&y, (void *)&dbg_buf};
     HIPCHK(hipLaunchKernel(k, dim3(P.ngroups), dim3(P.block_threads), args, lds_bytes, st));
@@ -940,13 +1075,17 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     o->lds_bytes = (int64_t)lds_bytes;
     o->mirror_entries = mirror_entries;
     o->bytes_algorithmic = P.nnz_low * (4 + s) + rows_ * (4 + 3 * s);
-    o->bytes_streamed = stream_len * s + slot_len * 2 + coo_len * (s + 4) + rows_ * (4 + 3 * s) +
+    o->far_entries = far_entries;
+    o->ngroups = P.ngroups;
+    o->bytes_streamed = stream_len * s + slot_len * 2 + coo_len * (s + 4) + far_len * (2 * s + 6) +
+                        rows_ * (4 + 3 * s) +
                         halo_slots * (4 + 2 * s) + rows_ * 8 /* slot_col, x, strip st */
                         + halo_slots * (4 + s)              /* fold: idx + strip ld  */
                         + (int64_t)(nfold + nsend) * (8 + 2 * s) + nslices * 16 +
                         (int64_t)P.tiles.size() * (int64_t)sizeof(Tile);
     o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + slot_col.bytes +
                                 rowinfo.bytes + diag.bytes + slice_meta.bytes + leadlane.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +
+                                fvals.bytes + frows.bytes + fcols.bytes +
                                 slots.bytes + strip.bytes + fold_rec.bytes +
                                 fold_idx.bytes + send_ptr.bytes + send_idx.bytes);
   }
@@ -1137,7 +1276,21 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     r.reorder = !(o->flags & CFS_HIP_FLAG_NO_REORDER);
     if (o->flags & CFS_HIP_FLAG_FORCE_CLUSTER) r.force_order = 2;
     if (o->flags & CFS_HIP_FLAG_SHARD_EXCHANGE) r.mirror_offblock = false;
+    if (o->flags & CFS_HIP_FLAG_HYB) r.hyb = true;
+    if (o->flags & CFS_HIP_FLAG_DETERMINISTIC) r.deterministic = true;
   }
+  // developer knobs (like CFS_HIP_MAX_SLOTS): far threshold, HYB on / off
+  if (const char *e = getenv("CFS_HIP_FAR_USES"))
+    if (atoi(e) > 0) r.far_uses = atoi(e);
+  if (const char *e = getenv("CFS_HIP_HYB")) r.hyb = atoi(e) != 0;
+  if (const char *e = getenv("CFS_HIP_DETERMINISTIC")) r.deterministic = atoi(e) != 0;
+  if (r.deterministic) { // one kernel shape, no far entries (see YWin)
+    r.hyb = false;
+    r.block_threads = 512;
+  }
+  if ((o && (o->flags & CFS_HIP_FLAG_NO_HYB)) || r.deterministic) r.hyb = false;
+  r.count_far = !r.hyb && !r.deterministic &&
+                !(o && (o->flags & (CFS_HIP_FLAG_NO_CALIBRATE | CFS_HIP_FLAG_NO_HYB)));
   // tuning knob for callers that cannot pass options (the C++ surface): LDS slots
   // per tile, like CFS_NUM_THREADS for the reference's partitions
   if (r.max_slots <= 0) {
@@ -1151,8 +1304,9 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
 // budget the options ask for: the persistent grid is sized to exactly one
 // resident wave of workgroups (a workgroup that has to wait for a slot would
 // run as a second round and double the launch time)
-template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
-  const void *k = (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true, true, cfs_plan::kSlotsPerThread>;
+template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb, bool det = false) {
+  const void *k = det ? (const void *)cfs_sym_tile_kernel<V, 512, 0, true, true, cfs_plan::kSlotsPerThread, true>
+                      : (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true, true, cfs_plan::kSlotsPerThread>;
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
   int rc = raise_lds_limit(k, dev);
@@ -1161,17 +1315,15 @@ template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb) {
   return 0;
 }
 template <typename V> static int query_residency(cfs_plan::Options &po) {
-  int block = po.block_threads > 0 ? po.block_threads : cfs_plan::kDefaultBlock;
-  int slots = po.max_slots > 0 ? po.max_slots : cfs_plan::kDefaultSlots;
-  const int slot_bytes = (int)sizeof(V) + 8;
-  if (slots > (160 * 1024 - 64) / slot_bytes) slots = (160 * 1024 - 64) / slot_bytes;
-  if (slots > cfs_plan::kSlotsPerThread * block) slots = cfs_plan::kSlotsPerThread * block;
-  if (slots < 64) slots = 64;
-  const size_t lds = (size_t)((slots + 63) / 64 * 64) * slot_bytes;
+  // the window the plan builder will allow (same rule: cfs_plan::chunk_layout)
+  const cfs_plan::ChunkLayout L = cfs_plan::chunk_layout<V>(1 << 30, po);
+  const int block = L.block;
+  const int slot_bytes = (int)sizeof(V) + (po.deterministic ? 16 : 8);
+  const size_t lds = (size_t)((L.max_slots + 63) / 64 * 64) * slot_bytes;
   int nb = 0, rc;
   switch (block) {
   case 256: rc = residency_one<V, 256>(lds, &nb); break;
-  case 512: rc = residency_one<V, 512>(lds, &nb); break;
+  case 512: rc = residency_one<V, 512>(lds, &nb, po.deterministic); break;
   case 1024: rc = residency_one<V, 1024>(lds, &nb); break;
   default: return 0; // build_plan reports the bad block size
   }
@@ -1232,47 +1384,47 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   // Both schedules are built and timed; the faster one is kept.
   const bool tuning = !(opt && (opt->flags & CFS_HIP_FLAG_NO_CALIBRATE)) &&
                       m->P.nnz_low >= (int64_t)2000000;
-  if (tuning && !m->P.perm.empty() && po.block_threads == 0 && po.max_slots == 0) {
-    DevBuf xb, yb;
-    if ((rc = xb.alloc((size_t)n * sizeof(V))) || (rc = yb.alloc((size_t)m->rows() * sizeof(V)))) {
-      delete m;
-      return rc;
+  // a measured step: build the alternative schedule, time ten SpMVs of each
+  // (interleaved, best of three), keep the faster one
+  DevBuf xb, yb;
+  auto time_spmv = [&](SymMatrix<V> *h, float *ms) -> int {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
+    int r2 = 0;
+    for (int it = 0; it < 3 && !r2; it++) r2 = h->spmv_local(yb.p, xb.p, nullptr, (hipStream_t)0, 3);
+    (void)hipEventRecord(a, (hipStream_t)0);
+    for (int it = 0; it < 10 && !r2; it++) r2 = h->spmv_local(yb.p, xb.p, nullptr, (hipStream_t)0, 3);
+    (void)hipEventRecord(b, (hipStream_t)0);
+    if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(ms, a, b) != hipSuccess) r2 = -1;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return r2;
+  };
+  auto try_alternative = [&](cfs_plan::Options &po2, cfs_plan::ScheduleSpace<V> *sp,
+                             const char *what) -> int {
+    if (!xb.p) {
+      int r2;
+      if ((r2 = xb.alloc((size_t)n * sizeof(V))) || (r2 = yb.alloc((size_t)m->rows() * sizeof(V))))
+        return r2;
+      (void)hipMemset(xb.p, 0x3f, xb.bytes); // small positive values
     }
-    (void)hipMemset(xb.p, 0x3f, xb.bytes); // small positive values
-    auto time_spmv = [&](SymMatrix<V> *h, float *ms) -> int {
-      hipEvent_t a, b;
-      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1;
-      int r2 = 0;
-      for (int it = 0; it < 3 && !r2; it++) r2 = h->spmv_local(yb.p, xb.p, nullptr, (hipStream_t)0, 3);
-      (void)hipEventRecord(a, (hipStream_t)0);
-      for (int it = 0; it < 10 && !r2; it++) r2 = h->spmv_local(yb.p, xb.p, nullptr, (hipStream_t)0, 3);
-      (void)hipEventRecord(b, (hipStream_t)0);
-      if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(ms, a, b) != hipSuccess) r2 = -1;
-      (void)hipEventDestroy(a);
-      (void)hipEventDestroy(b);
-      return r2;
-    };
-    cfs_plan::Options po2 = po;
-    po2.block_threads = 1024;
-    po2.max_slots = 2 * cfs_plan::kDefaultSlots;
     auto *alt = new SymMatrix<V>();
     alt->value_bytes = (int)sizeof(V);
     alt->device = cur_dev;
     float t_def = 0, t_alt = 0;
     bool ok = query_residency<V>(po2) == 0 &&
               cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                                      nranks > 1 ? row_splits : nullptr, po2, alt->P, &space) &&
+                                      nranks > 1 ? row_splits : nullptr, po2, alt->P, sp) &&
               alt->upload() == 0;
-    space = cfs_plan::ScheduleSpace<V>(); // release the schedule-space matrix
-    for (int round = 0; ok && round < 3; round++) { // interleaved, best of three each
+    for (int round = 0; ok && round < 3; round++) {
       float a = 0, b = 0;
       ok = time_spmv(m, &a) == 0 && time_spmv(alt, &b) == 0;
       t_def = round == 0 ? a : std::min(t_def, a);
       t_alt = round == 0 ? b : std::min(t_alt, b);
     }
     if (getenv("CFS_PLAN_VERBOSE"))
-      fprintf(stderr, "[cfs_hip] window shape: 512 x 2 per CU %.1f us, 1024 x 1 per CU %.1f us%s\n",
-              t_def * 100.0, t_alt * 100.0, ok ? "" : " (alternative not built)");
+      fprintf(stderr, "[cfs_hip] %s: current %.1f us, alternative %.1f us%s\n", what, t_def * 100.0,
+              t_alt * 100.0, ok ? "" : " (alternative not built)");
     if (ok && t_alt < 0.99f * t_def) {
       delete m;
       m = alt;
@@ -1280,65 +1432,31 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     } else {
       delete alt;
     }
-  }
-  // ---- XCD calibration (Tuning::Aggressive; CFS_HIP_FLAG_NO_CALIBRATE skips it) ----
-  // The eight XCDs do not stream at the same rate (measured: the groups dealt
-  // to XCD labels 4-6 finish ~7 % later than those of label 7, box after box)
-  // and the launch is as long as its slowest XCD.  Measure the mean finish time
-  // per XCD label with the timeline build of the kernel and re-cut the rows with
-  // per-XCD shares; keep the new schedule only if its launches end earlier.
-  // (a launch shorter than ~30 us -- fewer than 16M stored nonzeros -- is all start-up
-  // and tail: the XCD shares never paid there, pwtk stand-in 12.0 -> 12.3 us)
-  if (tuning && m->P.ngroups >= 64 && m->P.nnz_low >= (int64_t)16000000) {
-    const int G = m->P.ngroups, nper = G >> 3;
-    DevBuf xb, yb;
-    if ((rc = xb.alloc((size_t)n * sizeof(V))) || (rc = yb.alloc((size_t)m->rows() * sizeof(V)))) {
+    return 0;
+  };
+  if (tuning && !m->P.perm.empty() && po.block_threads == 0 && po.max_slots == 0) {
+    cfs_plan::Options po2 = po;
+    po2.block_threads = 1024;
+    po2.max_slots = 2 * cfs_plan::kDefaultSlots;
+    if ((rc = try_alternative(po2, &space, "window shape 512 x 2 per CU vs 1024 x 1"))) {
       delete m;
       return rc;
     }
-    HIPCHK(hipMemset(xb.p, 0x3f, xb.bytes)); // small positive values
-    std::vector<unsigned long long> st((size_t)G * 8);
-    auto measure = [&](SymMatrix<V> *h, double *xcd_end, double *kernel_end) -> int {
-      for (int k = 0; k < 8; k++) xcd_end[k] = 0;
-      *kernel_end = 0;
-      const int reps = 4;
-      for (int rep = 0; rep < reps; rep++) {
-        int ng = 0;
-        int r2 = h->timeline(yb.p, xb.p, st.data(), (int)st.size(), &ng);
-        if (r2) return r2;
-        unsigned long long t0 = ~0ull, t1 = 0;
-        for (int b = 0; b < G; b++) t0 = std::min(t0, st[(size_t)b * 8]);
-        for (int b = 0; b < G; b++) {
-          const double e = (double)(st[(size_t)b * 8 + 3] - t0);
-          xcd_end[b & 7] += e / (nper * reps);
-          t1 = std::max(t1, st[(size_t)b * 8 + 3]);
-        }
-        *kernel_end += (double)(t1 - t0) / reps;
-      }
-      return 0;
-    };
-    double e0[8], k0 = 0;
-    if (measure(m, e0, &k0) == 0) {
-      double mean = 0;
-      for (int k = 0; k < 8; k++) mean += e0[k] / 8;
-      po.force_order = m->P.perm.empty() ? 1 : 2;
-      po.group_share.assign(G, 1.0);
-      for (int g = 0; g < G; g++) po.group_share[g] = mean / e0[g / nper]; // slow XCD: less work
-      auto *nx = new SymMatrix<V>();
-      nx->value_bytes = (int)sizeof(V);
-      nx->device = cur_dev;
-      double e1[8], k1 = 0;
-      if (cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                                  nranks > 1 ? row_splits : nullptr, po, nx->P) &&
-          nx->P.ngroups == G && nx->upload() == 0 && measure(nx, e1, &k1) == 0 && k1 < k0) {
-        delete m;
-        m = nx;
-      } else {
-        delete nx;
-      }
-      if (getenv("CFS_PLAN_VERBOSE"))
-        fprintf(stderr, "[cfs_hip] XCD calibration: launch end %.1f us -> %.1f us (%s)\n", k0 / 100.0,
-                k1 / 100.0, k1 > 0 && k1 < k0 ? "kept" : "discarded");
+  }
+  space = cfs_plan::ScheduleSpace<V>(); // release the schedule-space matrix
+  // ---- HYB by measurement (Format::sss, Tuning::Aggressive) --------------------------
+  // A halo column that its tile uses once costs a slot, a slot-table entry, an x
+  // gather, a strip store and a fold entry for one nonzero; as a FAR entry the nonzero
+  // is stored twice and gathers x from L2.  Worth trying when such columns are a
+  // noticeable share of the matrix (ldoor stand-in: 6 % of the stored nonzeros, halo
+  // 2.55M -> 1.16M slots, 71 -> 66 us per SpMV; Flan, pwtk stand-ins: < 0.1 %, not tried).
+  const bool may_hyb = !(opt && (opt->flags & (CFS_HIP_FLAG_NO_HYB | CFS_HIP_FLAG_HYB))) && !po.hyb;
+  if (tuning && may_hyb && m->P.far_candidates * 33 >= m->P.nnz_low) {
+    cfs_plan::Options po2 = po;
+    po2.hyb = true;
+    if ((rc = try_alternative(po2, nullptr, "tile format vs HYB (far entries apart)"))) {
+      delete m;
+      return rc;
     }
   }
   m->ablate_mode = opt ? (opt->flags & CFS_HIP_FLAG_ABLATE_MASK) : 0;
@@ -1365,6 +1483,185 @@ int cfs_hip_sym_create_shard_f32(int n, const int *rowptr, const int *colind,
                                  const int *row_splits, const cfs_hip_options *opt,
                                  cfs_hip_sym_t *out) {
   return sym_create<float>(n, rowptr, colind, values, nranks, rank, row_splits, opt, out);
+}
+
+
+// ---------------------------------------------------------------------------
+// One host thread, N GPUs (the C++ surface with CFS_NUM_GPUS=N; reference knob:
+// CFS_NUM_THREADS, src/runtime.cpp:10-21): N mirrored 1-D row-block shards, one per
+// device, each on a stream of its own.  x and y stay where the caller put them (the
+// handle's HOME device); a shard on another device reads x and writes its rows of y
+// through peer access over xGMI.  An SpMV is ordered like any other work of the
+// caller's stream: the shard streams wait for an event recorded on it, it waits for
+// theirs.  (The performance path for several GPUs is one process per GPU, bench.py;
+// this is the drop-in path of an unmodified single-process caller.)
+// ---------------------------------------------------------------------------
+struct MultiSym : cfs_hip_sym_s {
+  std::vector<cfs_hip_sym_s *> shard;
+  std::vector<int> dev, splits;
+  std::vector<hipStream_t> st_;
+  std::vector<hipEvent_t> done_;
+  hipEvent_t start_ = nullptr;
+  int n_ = 0;
+  std::vector<int32_t> none_;
+  ~MultiSym() override {
+    for (size_t g = 0; g < shard.size(); g++) {
+      DeviceGuard dg(dev[g]);
+      if (g < st_.size() && st_[g]) (void)hipStreamSynchronize(st_[g]);
+      delete shard[g];
+      if (g < done_.size() && done_[g]) (void)hipEventDestroy(done_[g]);
+      if (g < st_.size() && st_[g]) (void)hipStreamDestroy(st_[g]);
+    }
+    if (start_) {
+      DeviceGuard dg(device);
+      (void)hipEventDestroy(start_);
+    }
+  }
+  int spmv_local(void *y, const void *x, void *, hipStream_t st, int phases) override {
+    HIPCHK(hipEventRecord(start_, st));
+    for (size_t g = 0; g < shard.size(); g++) {
+      DeviceGuard dg(dev[g]);
+      HIPCHK(hipStreamWaitEvent(st_[g], start_, 0));
+      int rc = shard[g]->spmv_local((char *)y + (size_t)splits[g] * value_bytes, x, nullptr, st_[g],
+                                    phases & (CFS_HIP_PHASE_TILES | CFS_HIP_PHASE_FOLD));
+      if (rc) return rc;
+      HIPCHK(hipEventRecord(done_[g], st_[g]));
+    }
+    for (size_t g = 0; g < shard.size(); g++) HIPCHK(hipStreamWaitEvent(st, done_[g], 0));
+    return 0;
+  }
+  int recv_fold(void *, const void *, hipStream_t) override { return 0; }
+  int set_recv(int, const int *) override { return set_err(CFS_HIP_ERR_ARG, "not a shard"); }
+  void stats(cfs_hip_sym_stats *o) override {
+    memset(o, 0, sizeof *o);
+    for (auto *h : shard) {
+      cfs_hip_sym_stats t;
+      h->stats(&t);
+      o->nnz_low += t.nnz_low;
+      o->nnz_diag += t.nnz_diag;
+      o->nnz_full += t.nnz_full;
+      o->ntiles += t.ntiles;
+      o->nslices += t.nslices;
+      o->halo_slots += t.halo_slots;
+      o->fold_rows += t.fold_rows;
+      o->bytes_algorithmic += t.bytes_algorithmic;
+      o->bytes_streamed += t.bytes_streamed;
+      o->device_bytes += t.device_bytes;
+      o->mirror_entries += t.mirror_entries;
+      o->far_entries += t.far_entries;
+      o->ngroups += t.ngroups;
+      o->max_slots_used = std::max(o->max_slots_used, t.max_slots_used);
+      o->lds_bytes = std::max(o->lds_bytes, t.lds_bytes);
+      o->block_threads = t.block_threads;
+      o->value_bytes = t.value_bytes;
+    }
+    o->n = n_;
+    o->row_begin = 0;
+    o->row_end = n_;
+  }
+  const std::vector<int32_t> &send_counts() override { return none_; }
+  const std::vector<int32_t> &send_rows() override { return none_; }
+  int n() override { return n_; }
+  int rows() override { return n_; }
+  int timeline(void *, const void *, unsigned long long *, int, int *) override {
+    return set_err(CFS_HIP_ERR_ARG, "no timeline for a multi-device handle");
+  }
+  int group_features(long long *, int, int *) override {
+    return set_err(CFS_HIP_ERR_ARG, "no group features for a multi-device handle");
+  }
+  int ngpus() const { return (int)shard.size(); }
+};
+
+template <typename V>
+static int sym_create_multi(int n, const int *rowptr, const int *colind, const V *values, int ngpus,
+                            const int *devices, const cfs_hip_options *opt, cfs_hip_sym_t *out) {
+  if (!out) return set_err(CFS_HIP_ERR_ARG, "out is NULL");
+  *out = nullptr;
+  if (ngpus < 1 || ngpus > cfs_rt::kMaxDevices) return set_err(CFS_HIP_ERR_ARG, "bad ngpus");
+  if (n < 0 || !rowptr) return set_err(CFS_HIP_ERR_ARG, "null CSR array");
+  int rc = ensure_init();
+  if (rc) return rc;
+  int home = 0, ndev = 0;
+  HIPCHK(hipGetDevice(&home));
+  HIPCHK(hipGetDeviceCount(&ndev));
+  auto *m = new MultiSym();
+  m->value_bytes = (int)sizeof(V);
+  m->device = home;
+  m->n_ = n;
+  m->splits.assign(ngpus + 1, 0);
+  cfs_plan::balanced_splits(n, rowptr, colind, ngpus, m->splits.data());
+  {
+    DeviceGuard dg(home);
+    if (hipEventCreateWithFlags(&m->start_, hipEventDisableTiming) != hipSuccess) {
+      delete m;
+      return set_err(CFS_HIP_ERR_DEVICE, "hipEventCreate failed");
+    }
+  }
+  cfs_hip_options o2;
+  memset(&o2, 0, sizeof o2);
+  if (opt) o2 = *opt;
+  o2.flags &= ~CFS_HIP_FLAG_SHARD_EXCHANGE; // one process: mirrored shards, nothing to exchange
+  for (int g = 0; g < ngpus; g++) {
+    // devices[g] when given, else the visible devices round-robin (several shards may
+    // share a device: that is how a one-GPU box rehearses the path)
+    const int d = devices ? devices[g] : (home + g) % std::max(1, ndev);
+    if (d < 0 || d >= ndev) {
+      delete m;
+      return set_err(CFS_HIP_ERR_ARG, "bad device index");
+    }
+    DeviceGuard dg(d);
+    if (d != home) { // the shard reads x / writes y on the home device
+      int can = 0;
+      (void)hipDeviceCanAccessPeer(&can, d, home);
+      hipError_t e = can ? hipDeviceEnablePeerAccess(home, 0) : hipErrorPeerAccessUnsupported;
+      if (e == hipErrorPeerAccessAlreadyEnabled) {
+        (void)hipGetLastError();
+        e = hipSuccess;
+      }
+      if (e != hipSuccess) {
+        delete m;
+        return set_err(CFS_HIP_ERR_DEVICE, "device " + std::to_string(d) + " cannot access device " +
+                                               std::to_string(home) + " (peer access)");
+      }
+    }
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      delete m;
+      return set_err(CFS_HIP_ERR_DEVICE, "stream / event creation failed");
+    }
+    cfs_hip_sym_t h = nullptr;
+    rc = sym_create<V>(n, rowptr, colind, values, ngpus, g, m->splits.data(), &o2, &h);
+    m->dev.push_back(d);
+    m->st_.push_back(st);
+    m->done_.push_back(ev);
+    if (rc) {
+      std::string e = cfs_rt::last_error();
+      m->shard.push_back(nullptr);
+      delete m;
+      return set_err(rc, e);
+    }
+    m->shard.push_back(h);
+  }
+  *out = m;
+  return 0;
+}
+int cfs_hip_sym_create_multi_f64(int n, const int *rowptr, const int *colind, const double *values,
+                                 int ngpus, const int *devices, const cfs_hip_options *opt,
+                                 cfs_hip_sym_t *out) {
+  return sym_create_multi<double>(n, rowptr, colind, values, ngpus, devices, opt, out);
+}
+int cfs_hip_sym_create_multi_f32(int n, const int *rowptr, const int *colind, const float *values,
+                                 int ngpus, const int *devices, const cfs_hip_options *opt,
+                                 cfs_hip_sym_t *out) {
+  return sym_create_multi<float>(n, rowptr, colind, values, ngpus, devices, opt, out);
+}
+int cfs_hip_sym_num_gpus(cfs_hip_sym_t h, int *ngpus) {
+  if (!h || !ngpus) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  auto *m = dynamic_cast<MultiSym *>(h);
+  *ngpus = m ? m->ngpus() : 1;
+  return 0;
 }
 
 int cfs_hip_sym_balanced_splits(int n, const int *rowptr, const int *colind, int nranks,
@@ -1490,9 +1787,9 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   if (!cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
                                nranks > 1 ? row_splits : nullptr, to_opts(opt), P))
     return set_err(plan_error_code(P.error), P.error);
-  std::vector<int32_t> r, c;
-  std::vector<V> v;
-  cfs_plan::decode_plan(P, r, c, v);
+  std::vector<int32_t> r, c, fr, fc, ur, uc;
+  std::vector<V> v, fv, uv;
+  cfs_plan::decode_plan(P, r, c, v, &fr, &fc, &fv, &ur, &uc, &uv);
   rep->ntiles = (int)P.tiles.size();
   rep->ngroups = P.ngroups;
   rep->nslices = (int64_t)P.slice_meta.size();
@@ -1503,6 +1800,7 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   rep->fold_rows = (int64_t)P.fold_row.size();
   rep->remote_vals = (int64_t)P.send_row.size();
   rep->decoded = (int64_t)r.size();
+  rep->far_entries = P.far_entries;
   // (1) decoded triples == strict lower triangle of the owned rows, as
   // multisets of (row, col, value bits): clustering moves an entry to the row
   // of its later end and back, and reorders entries inside rows
@@ -1521,6 +1819,16 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
       memcpy(&u, &x, sizeof(V));
       return u;
     };
+    { // HYB: the mirrored far entries are exactly the far entries of the lower side
+      std::vector<Tr> F, U;
+      for (size_t k = 0; k < fr.size(); k++) F.push_back(Tr{fr[k], fc[k], bits(fv[k])});
+      for (size_t k = 0; k < ur.size(); k++) U.push_back(Tr{ur[k], uc[k], bits(uv[k])});
+      std::sort(F.begin(), F.end());
+      std::sort(U.begin(), U.end());
+      if (F.size() != U.size() || (int64_t)F.size() != P.far_entries) bad++;
+      for (size_t k = 0; k < std::min(F.size(), U.size()); k++)
+        if (F[k] != U[k]) bad++;
+    }
     std::vector<Tr> A, B;
     A.reserve(r.size());
     B.reserve(r.size());
@@ -1594,6 +1902,7 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   // (3) groups partition the tiles; tiles partition the rows
   {
     if (P.group_ptr.front() != 0 || P.group_ptr.back() != (int)P.tiles.size()) bad++;
+    if ((int)P.group_ptr.size() != P.ngroups + 1 || P.ngroups % 8) bad++;
     for (size_t g = 1; g < P.group_ptr.size(); g++)
       if (P.group_ptr[g] < P.group_ptr[g - 1]) bad++;
     int row = P.row_begin;

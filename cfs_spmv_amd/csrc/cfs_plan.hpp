@@ -5,9 +5,10 @@
 //
 // What the reference does at this point (include/matrix/csr_matrix.tpp):
 //   partition_by_nrows :403-435, conflict_free_aposteriori :1204-1639,
-//   color_greedy :2009-2363 -- rows are split among T threads, the strict
-//   lower triangle + diagonal are extracted per thread, 16-row blocks are
-//   coloured so that no two threads update the same y element in a phase.
+//   color_greedy :2009-2363, split_by_bandwidth :312-401 -- rows are split among
+//   T threads, the strict lower triangle + diagonal are extracted per thread,
+//   16-row blocks are coloured so that no two threads update the same y element
+//   in a phase; HYB moves entries far from the diagonal to an unsymmetric side CSR.
 // What this build does instead (MI355X-first, not a translation):
 //   * rows are cut into TILES of consecutive rows; one 64-lane wavefront lane
 //     owns one row, so the row-side sum y_i needs no reduction at all;
@@ -29,6 +30,12 @@
 //     private strip with plain coalesced stores and a tiny second kernel folds
 //     the strips into y through an inverted index in a fixed order (no global
 //     atomics, no barriers between colours);
+//   * FAR entries (Format::hyb, the reference's split_by_bandwidth idea): a halo
+//     column that a tile uses only once costs a slot, a slot-table entry, an x
+//     gather, a strip store and a fold entry for ONE nonzero.  Such an entry leaves
+//     the symmetric tile format: it is stored by BOTH tiles it touches, each as
+//     (value, own row slot, global column), and processed one-sided -- y_l[row] +=
+//     a * x[col] with x gathered from global memory: no slot, no strip, no fold;
 //   * tiles are dealt to persistent workgroups in contiguous, cost-balanced
 //     groups, groups of neighbouring rows on the same XCD (blockIdx % 8);
 //   * a 1-D row block of a sharded matrix stores its off-block entries
@@ -41,6 +48,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -58,10 +66,7 @@ struct Options {
   bool reorder = true; // cluster rows so that tiles are compact in every direction
   int force_order = 0; // 0 = pick the order with fewer halo slots, 1 = natural, 2 = clustered
   // relative work share of every persistent group (size = number of groups,
-  // any positive scale); empty = equal shares.  The creator's XCD calibration
-  // fills it with one value per XCD: the eight XCDs do not stream at equal rates.
-  // (Per-GROUP shares from per-workgroup finish times do not help: workgroups of
-  // one CU finish in dispatch order whatever their shares, the CU total counts.)
+  // any positive scale); empty = equal shares.
   std::vector<double> group_share;
   // Shards (nranks > 1): off-block entries are stored by BOTH ranks they touch and
   // processed one-sided (row side only): a row of the block also carries its
@@ -72,14 +77,22 @@ struct Options {
   bool mirror_offblock = true;
   int wg_per_cu = 0; // measured residency of the tile kernel (0 = estimate)
   int num_cus = 0;   // compute units of the device (0 = 256, MI355X)
+  // HYB: entries whose halo column is used at most `far_uses` times by their tile
+  // become FAR entries (see the header comment)
+  bool hyb = false;
+  int far_uses = 1;
+  bool count_far = false; // HYB off: still report SymPlan::far_candidates
+  // bit-reproducible results: the y window takes two 8-byte integer words per slot
+  // (fixed-point sums, integer LDS atomics) instead of one fp64 word; no far entries
+  bool deterministic = false;
 };
 
 // one tile = one pass of a workgroup through prologue / slices / epilogue
 struct Tile {
-  int32_t row0;       // first own row (global index)
+  int32_t row0;       // first own row (global index, schedule space)
   int32_t nown;       // own rows = own slots [0, nown)
   int32_t nslots;     // nown + halo slots
-  int32_t nslices;    // ceil(nvrows / 64)
+  int32_t nvrows;     // virtual rows (>= nown: long rows are split over lanes)
   int32_t halo_off;   // offset of this tile's halo in halo_col[] and strip[]
   int32_t slice_base; // offset of this tile's slices in slice_meta[]
   int64_t nnz_off;    // offset of this tile's value stream in vals[]
@@ -88,11 +101,16 @@ struct Tile {
   int32_t ncoo;       // leftover entries (len % 4 per row)
   int32_t slot_off;   // offset of this tile's slots in slot_col[]
   int32_t vrow_off;   // offset of this tile's virtual rows in rowinfo[] / diag[]
-  int32_t nvrows;     // virtual rows (>= nown: long rows are split over lanes)
   int32_t ny;         // slots with a y window entry: own rows + in-block halo; slots
                       // [ny, nslots) are off-block columns of a mirrored shard (x only)
+  int32_t far_off;    // offset of this tile's FAR section in fvals/frows/fcols
+  int32_t nfar;       // far entries: [0, nfar_low) belong to own rows' lower triangle,
+  int32_t nfar_low;   // [nfar_low, nfar) are the mirror images of other tiles' far entries
+  int32_t nslices;    // ceil(nvrows / 64)
+  int32_t aexp;       // every stored value of the tile (diagonal included) is < 2^aexp in
+                      // magnitude: the scale of the deterministic build's fixed-point sums
 };
-static_assert(sizeof(Tile) == 64, "Tile must stay 64 bytes");
+static_assert(sizeof(Tile) == 80, "Tile must stay 80 bytes");
 
 struct SliceMeta {
   uint32_t voff;      // entry offset of the slice's first packet in the tile's value stream
@@ -143,7 +161,11 @@ template <typename V> struct SymPlan {
   std::vector<int> row_splits;
   int64_t nnz_low = 0, nnz_diag = 0, nnz_full = 0;
   // knobs actually used
-  int max_slots = 0, block_threads = 0, ngroups = 0, lds_slots = 0;
+  int max_slots = 0, block_threads = 0, lds_slots = 0;
+  bool deterministic = false;
+  // launch shape: `ngroups` persistent workgroups (a multiple of 8); workgroup b runs
+  // group (b % 8) * (ngroups / 8) + b / 8
+  int ngroups = 0;
   // schedule
   std::vector<Tile> tiles;
   std::vector<int32_t> group_ptr;   // [ngroups+1] tiles of persistent group g
@@ -164,6 +186,11 @@ template <typename V> struct SymPlan {
   std::vector<V> cvals;             // [coo_len] COO leftovers, packet layout
   std::vector<uint16_t> crows, ccols; // [coo_len]
   int64_t coo_len = 0, coo_entries = 0;
+  // FAR sections (HYB): value, own row slot, ORIGINAL global column; packet layout
+  std::vector<V> fvals;
+  std::vector<uint16_t> frows;
+  std::vector<int32_t> fcols;
+  int64_t far_len = 0, far_entries = 0; // padded length; far nonzeros (each stored twice)
   // halo fold (destinations inside [row_begin,row_end)), local row indices
   std::vector<int32_t> fold_row, fold_ptr, fold_idx;
   // remote contributions (destinations < row_begin), global row indices
@@ -176,6 +203,7 @@ template <typename V> struct SymPlan {
   bool mirrored = false;    // shard built with mirror_offblock (no sends)
   int64_t mirror_entries = 0; // one-sided entries stored for rows of higher ranks
   int64_t onesided_slots = 0; // halo slots without a y window
+  int64_t far_candidates = 0; // entries the first cut marked as far (before the final cut)
   std::vector<int32_t> tile_rounds; // [T] packet rounds of a tile: sum over its slices of the
                                     // longest lane's packet count (issue cost, not bytes)
   std::string error;
@@ -235,56 +263,103 @@ inline void balanced_splits(int n, const int *rowptr, const int *colind,
   row_splits[nranks] = n;
 }
 
-// Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the full
-// CSR.  Returns false (plan.error set) when the matrix cannot be scheduled.
-template <typename V>
-bool build_plan_core(int n, const int *rowptr, const int *colind, const V *values,
-                     int nranks, int rank, const int *row_splits_in,
-                     const Options &opt, const std::vector<int32_t> *chunks_in,
-                     const std::vector<int32_t> *perm_in, SymPlan<V> &P, bool cut_only = false) {
-  P = SymPlan<V>();
-  P.n = n;
-  P.nranks = nranks;
-  P.rank = rank;
-  if (row_splits_in)
-    P.row_splits.assign(row_splits_in, row_splits_in + nranks + 1);
-  else
-    P.row_splits = {0, n};
-  const int rb = P.row_begin = P.row_splits[rank];
-  const int re = P.row_end = P.row_splits[rank + 1];
-  if (rb < 0 || re > n || rb > re) {
-    P.error = "bad row_splits";
-    return false;
+// The launch layout: `ngroups` cost-balanced chunks of rows, one per persistent
+// workgroup -- as many as are co-resident, fewer for a small matrix.
+struct ChunkLayout {
+  int block = 0, max_slots = 0, ngroups = 0;
+  int nchunks() const { return ngroups; }
+  // relative cost share of every chunk, in chunk order
+  std::vector<double> shares(const Options &opt) const {
+    std::vector<double> s((size_t)ngroups, 1.0);
+    if ((int)opt.group_share.size() == ngroups)
+      for (int g = 0; g < ngroups; g++) s[g] = std::max(opt.group_share[g], 1e-9);
+    return s;
   }
-  const int rows = re - rb;
-  const int slot_bytes = (int)sizeof(V) + 8; // x window in V, y window always fp64
-  const int hard_slots = (160 * 1024 - 64) / slot_bytes; // 16 B of static LDS (slice tickets)
+};
+template <typename V> inline ChunkLayout chunk_layout(int rows, const Options &opt) {
+  ChunkLayout L;
+  // x window in V, y window always fp64 (two integer words in the deterministic build)
+  const int slot_bytes = (int)sizeof(V) + (opt.deterministic ? 16 : 8);
+  L.block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
   int max_slots = opt.max_slots > 0 ? opt.max_slots : kDefaultSlots;
-  if (max_slots > hard_slots) max_slots = hard_slots;
-  if (max_slots > 65536) max_slots = 65536;
-  if (max_slots < 64) max_slots = 64;
-  P.max_slots = max_slots;
-  int block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
-  if (block != 256 && block != 512 && block != 1024) {
-    P.error = "block_threads must be 256, 512 or 1024";
-    return false;
-  }
-  P.block_threads = block;
-  if (max_slots > kSlotsPerThread * block) max_slots = kSlotsPerThread * block;
-  P.max_slots = max_slots;
-  const int64_t max_tile_nnz =
-      opt.max_tile_nnz > 0 ? opt.max_tile_nnz : (int64_t)1 << 30;
+  if (opt.deterministic && opt.max_slots <= 0) // still two workgroups per CU
+    max_slots = std::min(max_slots, (160 * 1024 / 2 - 64) / slot_bytes / 64 * 64);
+  max_slots = std::min(max_slots, (160 * 1024 - 64) / slot_bytes); // 16 B static LDS (tickets)
+  max_slots = std::min(max_slots, 65536);
+  max_slots = std::min(max_slots, kSlotsPerThread * std::max(L.block, 64));
+  L.max_slots = std::max(max_slots, 64);
+  const int64_t lds_budget = (int64_t)((L.max_slots + 63) / 64 * 64) * slot_bytes + kStaticLds;
+  // co-resident workgroups per CU: LDS, the 2048-thread limit and -- the tile
+  // kernel is held to 128 VGPRs -- 4 waves per SIMD; the creator passes the
+  // occupancy the runtime reports for the real kernel when a device is there
+  int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / lds_budget, (4 * 4 * 64) / std::max(L.block, 64));
+  if (opt.wg_per_cu > 0) wg_per_cu = opt.wg_per_cu;
+  if (wg_per_cu < 1) wg_per_cu = 1;
+  const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
+  int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
+  const int by_rows = ((rows + min_rows_per_group() - 1) / min_rows_per_group() + 7) / 8 * 8;
+  if (ngroups > by_rows) ngroups = by_rows;
+  if (ngroups < 8) ngroups = 8;
+  L.ngroups = ngroups;
+  return L;
+}
+
+// ---------------------------------------------------------------------------
+// The builder: the phases of one schedule build, in the order they run
+//   count_rows   stored (near) entries per row, cost prefix
+//   cut_chunks   rows -> cost-balanced chunks, one per persistent workgroup
+//   cut_tiles    chunks -> LDS-sized tiles (greedy, halo slot budget)
+//   mark_far     HYB: halo columns a tile uses <= far_uses times -> far entries
+//   resolve_far  after a cut: far entries per row, both sides
+//   size_streams virtual rows, slices, leaders, stream / slot / COO / far offsets
+//   fill_streams packets, slot tables, COO and FAR sections
+//   fold_index   strips -> destination rows (local fold / sends of a shard)
+//   finish       LDS window, per-chunk first tiles, original numbering
+// ---------------------------------------------------------------------------
+template <typename V> struct Builder {
+  const int n;
+  const int *rowptr, *colind;
+  const V *values;
+  const int nranks, rank;
+  const Options &opt;
+  const std::vector<int32_t> *chunks_in, *perm_in;
+  SymPlan<V> &P;
+  int rb = 0, re = 0, rows = 0;
+  bool mirror = false;
+  ChunkLayout L;
+  int64_t max_tile_nnz = 0;
+  std::vector<int32_t> lcnt, firstcol, farL, farU; // per local row
+  std::vector<uint64_t> farbits;                   // one bit per CSR position (empty: none)
+  std::vector<int64_t> cost;                       // [rows+1] prefix of the row costs
+  std::vector<int32_t> chunk;                      // [nchunks+1] row boundaries
+  std::vector<int32_t> tile_of_row;                // local row -> tile
+  std::vector<int64_t> tile_len, tile_slen;
+  bool mirror_fail = false, dup_error = false;
+  PhaseTimer pt;
+
+  struct VRow {
+    int32_t r, k0, a; // local row, first packet of the chunk, packets in the chunk
+  };
+
+  Builder(int n_, const int *rp, const int *ci, const V *va, int nranks_, int rank_,
+          const Options &o, const std::vector<int32_t> *chunks, const std::vector<int32_t> *perm,
+          SymPlan<V> &plan)
+      : n(n_), rowptr(rp), colind(ci), values(va), nranks(nranks_), rank(rank_), opt(o),
+        chunks_in(chunks), perm_in(perm), P(plan) {}
+
+  bool is_far(int64_t j) const { return !farbits.empty() && ((farbits[j >> 6] >> (j & 63)) & 1); }
   // which entries of row i does the schedule store?  The strict lower triangle,
   // and -- for a mirrored shard -- the entries right of the block (rows of higher
   // ranks that hold a_ci: their transposed update of y_i is computed HERE)
-  const bool mirror = opt.mirror_offblock && nranks > 1;
-  P.mirrored = mirror;
-  auto stored = [&](int i, int c) { return c < i || (mirror && c >= re); };
+  bool stored(int i, int c) const { return c < i || (mirror && c >= re); }
+  // ... in the packet / COO streams (a far entry lives in the far section)
+  bool near(int i, int64_t j) const { return stored(i, colind[j]) && !is_far(j); }
+  int orig(int c) const { return (perm_in && c >= rb && c < re) ? (*perm_in)[c - rb] : c; }
+
   // natural order: `values` is the caller's full CSR and the value of a mirrored
   // entry (i, c), c >= re, is the LOWER entry (c, i) -- all the reference's SSS
   // path reads.  Clustered order (perm_in): the caller resolved it already.
-  bool mirror_fail = false;
-  auto val_at = [&](int i, int j) -> V {
+  V val_at(int i, int j) {
     const int c = colind[j];
     if (!mirror || c < re || perm_in) return values[j];
     int b = rowptr[c], e = rowptr[c + 1], l = b, r = e;
@@ -299,94 +374,123 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 #pragma omp atomic write
     mirror_fail = true; // structurally unsymmetric input
     return V(0);
-  };
+  }
 
-  // ---- lower counts -----------------------------------------------------
-  std::vector<int32_t> lcnt(rows, 0), firstcol(rows, -1);
-  int64_t nnz_low = 0, nnz_diag = 0, nnz_mirror = 0, mirror_dup = 0;
-#pragma omp parallel for schedule(static) reduction(+ : nnz_low, nnz_diag, nnz_mirror, mirror_dup) num_threads(host_threads())
-  for (int i = rb; i < re; i++) {
-    int c = 0, up = 0, prev_up = -1;
-    bool dup = false;
-    for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-      if (colind[j] < i) c++;
-      else if (colind[j] == i) nnz_diag++;
-      else if (mirror && colind[j] >= re) {
-        if (colind[j] <= prev_up) dup = true; // duplicate / unsorted: cannot pair with (c, i)
-        prev_up = colind[j];
-        up++;
+  bool setup(const int *row_splits_in) {
+    P = SymPlan<V>();
+    P.n = n;
+    P.nranks = nranks;
+    P.rank = rank;
+    if (row_splits_in) P.row_splits.assign(row_splits_in, row_splits_in + nranks + 1);
+    else P.row_splits = {0, n};
+    rb = P.row_begin = P.row_splits[rank];
+    re = P.row_end = P.row_splits[rank + 1];
+    if (rb < 0 || re > n || rb > re) {
+      P.error = "bad row_splits";
+      return false;
+    }
+    rows = re - rb;
+    const int block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
+    if (block != 256 && block != 512 && block != 1024) {
+      P.error = "block_threads must be 256, 512 or 1024";
+      return false;
+    }
+    L = chunk_layout<V>(rows, opt);
+    if (chunks_in) { // the caller's clusters: same layout rule, boundaries given
+      if ((int)chunks_in->size() != L.nchunks() + 1) {
+        P.error = "internal: chunk count does not match the launch layout";
+        return false;
       }
     }
-    lcnt[i - rb] = c + up;
-    {
-      int fc = -1; // first stored column: rows of one mesh node share it (sibling test)
-      for (int j = rowptr[i]; j < rowptr[i + 1] && fc < 0; j++)
-        if (stored(i, colind[j])) fc = colind[j];
-      firstcol[i - rb] = fc;
-    }
-    nnz_low += c;
-    nnz_mirror += up;
-    if (dup) mirror_dup++;
+    P.block_threads = L.block;
+    P.max_slots = L.max_slots;
+    P.ngroups = L.ngroups;
+    P.deterministic = opt.deterministic;
+    max_tile_nnz = opt.max_tile_nnz > 0 ? opt.max_tile_nnz : (int64_t)1 << 30;
+    mirror = opt.mirror_offblock && nranks > 1;
+    P.mirrored = mirror;
+    return true;
   }
-  if (mirror_dup) {
-    P.error = "mirror: duplicate or unsorted off-block entries";
-    return false;
-  }
-  P.mirror_entries = nnz_mirror;
-  P.nnz_low = nnz_low;
-  P.nnz_diag = nnz_diag;
-  P.nnz_full = 2 * nnz_low + nnz_diag;
-  PhaseTimer pt;
-  pt.lap("core: lower counts");
 
-  // ---- persistent groups first, tiles inside them ----------------------------
-  // A CU only streams ~1/256 of the HBM bandwidth, so the launch is as long as
-  // its most loaded CU: rows are first cut into `ngroups` contiguous chunks of
-  // equal streamed bytes (one chunk per persistent workgroup, as many
-  // workgroups as are co-resident), and only then into LDS-sized tiles that
-  // never straddle a chunk.
-  {
-    const int64_t lds_budget = (int64_t)((max_slots + 63) / 64 * 64) * slot_bytes + kStaticLds;
-    // co-resident workgroups per CU: LDS, the 2048-thread limit and -- the tile
-    // kernel needs ~100-128 VGPRs -- 4 waves per SIMD; the creator passes the
-    // occupancy the runtime reports for the real kernel when a device is there
-    int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / lds_budget, (4 * 4 * 64) / block);
-    if (opt.wg_per_cu > 0) wg_per_cu = opt.wg_per_cu;
-    if (wg_per_cu < 1) wg_per_cu = 1;
-    const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
-    int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
-    int by_rows = ((rows + min_rows_per_group() - 1) / min_rows_per_group() + 7) / 8 * 8;
-    if (ngroups > by_rows) ngroups = by_rows;
-    if (ngroups < 8) ngroups = 8;
-    P.ngroups = ngroups;
-    std::vector<int64_t> cost(rows + 1, 0);
+  // ---- stored entries per row (the far ones apart), cost prefix --------------------
+  bool count_rows() {
+    lcnt.assign(rows, 0);
+    firstcol.assign(rows, -1);
+    int64_t nnz_low = 0, nnz_diag = 0, nnz_mirror = 0, mirror_dup = 0;
+#pragma omp parallel for schedule(static) reduction(+ : nnz_low, nnz_diag, nnz_mirror, mirror_dup) num_threads(host_threads())
+    for (int i = rb; i < re; i++) {
+      int c = 0, up = 0, prev_up = -1, nearc = 0, fc = -1;
+      bool dup = false;
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        const int col = colind[j];
+        if (col < i) c++;
+        else if (col == i) nnz_diag++;
+        else if (mirror && col >= re) {
+          if (col <= prev_up) dup = true; // duplicate / unsorted: cannot pair with (c, i)
+          prev_up = col;
+          up++;
+        }
+        if (near(i, j)) {
+          nearc++;
+          // first stored column: rows of one mesh node share it (sibling test)
+          if (fc < 0) fc = col;
+        }
+      }
+      lcnt[i - rb] = nearc;
+      firstcol[i - rb] = fc;
+      nnz_low += c;
+      nnz_mirror += up;
+      if (dup) mirror_dup++;
+    }
+    if (mirror_dup) {
+      P.error = "mirror: duplicate or unsorted off-block entries";
+      return false;
+    }
+    P.mirror_entries = nnz_mirror;
+    P.nnz_low = nnz_low;
+    P.nnz_diag = nnz_diag;
+    P.nnz_full = 2 * nnz_low + nnz_diag;
+    cost.assign((size_t)rows + 1, 0);
+    const bool far = !farL.empty();
     for (int r = 0; r < rows; r++)
       cost[r + 1] = cost[r] + (int64_t)lcnt[r] * (int64_t)(sizeof(V) + 2) +
+                    (far ? (int64_t)(farL[r] + farU[r]) * (int64_t)(2 * sizeof(V) + 6) : 0) +
                     (int64_t)(4 + 3 * sizeof(V)) + 2 * (int64_t)sizeof(V);
-    std::vector<int32_t> chunk(ngroups + 1, re);
-    chunk[0] = rb;
+    return true;
+  }
+
+  // ---- rows -> chunks of equal streamed bytes ------------------------------------------
+  // A CU only streams ~1/256 of the HBM bandwidth, so the launch is as long as
+  // its most loaded CU: rows are first cut into contiguous chunks of equal streamed
+  // bytes (one chunk per persistent workgroup, as many workgroups as are
+  // co-resident), and only then into LDS-sized tiles that never straddle a chunk.
+  void cut_chunks() {
+    const int nc = L.nchunks();
     if (chunks_in) {
-      ngroups = (int)chunks_in->size() - 1;
-      P.ngroups = ngroups;
       chunk = *chunks_in;
+      return;
     }
-    std::vector<double> cumshare(ngroups + 1, 0.0);
-    for (int g = 0; g < ngroups; g++)
-      cumshare[g + 1] = cumshare[g] + ((int)opt.group_share.size() == ngroups
-                                           ? std::max(opt.group_share[g], 1e-9) : 1.0);
-    for (int g = 1; !chunks_in && g < ngroups; g++) {
-      int64_t target = (int64_t)((double)cost[rows] * (cumshare[g] / cumshare[ngroups]));
+    chunk.assign((size_t)nc + 1, re);
+    chunk[0] = rb;
+    const std::vector<double> share = L.shares(opt);
+    std::vector<double> cum((size_t)nc + 1, 0.0);
+    for (int c = 0; c < nc; c++) cum[c + 1] = cum[c] + share[c];
+    for (int c = 1; c < nc; c++) {
+      const int64_t target = (int64_t)((double)cost[rows] * (cum[c] / cum[nc]));
       int r = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
       if (r > rows) r = rows;
-      if (rb + r < chunk[g - 1]) r = chunk[g - 1] - rb;
-      chunk[g] = rb + r;
+      if (rb + r < chunk[c - 1]) r = chunk[c - 1] - rb;
+      chunk[c] = rb + r;
     }
-    chunk[ngroups] = re;
+    chunk[nc] = re;
+  }
 
-    // greedy cut of rows [r0, r1) under the slot budget and a cost cap; returns
-    // false on an unschedulable row.  Chunks are independent: one thread each,
-    // with its own "column already counted for tile id" stamps.
-    std::vector<std::vector<Tile>> per_group(ngroups);
+  // ---- chunks -> tiles: greedy cut under the slot budget and a cost cap ---------------
+  // Chunks are independent: one thread each, with its own "column already counted for
+  // tile id" stamps.  A far entry takes no slot.
+  bool cut_tiles(std::vector<Tile> &tiles, std::vector<int32_t> &group_ptr) {
+    const int nc = L.nchunks(), max_slots = L.max_slots;
+    std::vector<std::vector<Tile>> per_chunk(nc);
     std::string cut_error;
 #pragma omp parallel num_threads(host_threads())
     {
@@ -403,9 +507,10 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
           while (row < r1) {
             int newh = 0, len = 0;
             for (int j = rowptr[row]; j < rowptr[row + 1]; j++) {
-              int c = colind[j];
+              const int c = colind[j];
               if (!stored(row, c)) continue;
               len++;
+              if (is_far(j)) continue;
               if ((c < t.row0 || c >= re) && stamp[c] != tid) {
                 stamp[c] = tid;
                 newh++;
@@ -415,9 +520,9 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
               err = "row with more than 65535 lower entries";
               return false;
             }
-            bool fits = (nown + 1 + nhalo + newh <= max_slots) &&
-                        (nnz + len <= max_tile_nnz || nown == 0) && nown < 65535 &&
-                        (cost[row + 1 - rb] - c0 <= cap || nown == 0);
+            const bool fits = (nown + 1 + nhalo + newh <= max_slots) &&
+                              (nnz + len <= max_tile_nnz || nown == 0) && nown < 65535 &&
+                              (cost[row + 1 - rb] - c0 <= cap || nown == 0);
             if (!fits) {
               if (nown == 0) {
                 err = "a single row needs more LDS slots than max_slots "
@@ -433,17 +538,16 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
           }
           t.nown = nown;
           t.nslots = nown + nhalo;
-          t.nslices = (nown + kLanes - 1) / kLanes;
           out.push_back(t);
           tid++;
         }
         return true;
       };
 #pragma omp for schedule(dynamic, 1)
-      for (int g = 0; g < ngroups; g++) {
+      for (int g = 0; g < nc; g++) {
         const int r0 = chunk[g], r1 = chunk[g + 1];
         if (r0 >= r1 || !err.empty()) continue;
-        std::vector<Tile> &tmp = per_group[g];
+        std::vector<Tile> &tmp = per_chunk[g];
         if (!cut(r0, r1, (int64_t)1 << 60, tmp)) continue;
         if (tmp.size() > 1) { // even the tiles of a chunk out (less halo, same count)
           const int64_t cc = cost[r1 - rb] - cost[r0 - rb];
@@ -461,19 +565,84 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
       P.error = cut_error;
       return false;
     }
-    P.group_ptr.assign(ngroups + 1, 0);
-    for (int g = 0; g < ngroups; g++) {
-      P.group_ptr[g] = (int32_t)P.tiles.size();
-      P.tiles.insert(P.tiles.end(), per_group[g].begin(), per_group[g].end());
+    tiles.clear();
+    group_ptr.assign((size_t)nc + 1, 0);
+    for (int g = 0; g < nc; g++) {
+      group_ptr[g] = (int32_t)tiles.size();
+      tiles.insert(tiles.end(), per_chunk[g].begin(), per_chunk[g].end());
     }
-    P.group_ptr[ngroups] = (int32_t)P.tiles.size();
-  }
-  const int T = (int)P.tiles.size();
-  pt.lap("core: cut tiles");
-  if (cut_only) { // the caller only wants to compare halo sizes of two row orders
-    P.nhalo = 0;
-    for (const Tile &t : P.tiles) P.nhalo += t.nslots - t.nown;
+    group_ptr[nc] = (int32_t)tiles.size();
     return true;
+  }
+
+  // ---- HYB, first half: which entries leave the tile format? -----------------------------
+  // For the tiles of a first cut: an in-block halo column that its tile uses at most
+  // far_uses times.  (Off-block columns of a shard keep their slots: they are
+  // one-sided already, or their sums are sent to the owner.)
+  void mark_far(const std::vector<Tile> &tiles) {
+    const int64_t nnz = rowptr[n];
+    farbits.assign((size_t)(nnz + 63) / 64 + 1, 0);
+    const int T = (int)tiles.size(), thr = std::max(1, opt.far_uses);
+    int64_t marked = 0;
+#pragma omp parallel num_threads(host_threads()) reduction(+ : marked)
+    {
+      std::vector<int32_t> uses(n > 0 ? n : 1, 0);
+      std::vector<int32_t> touched;
+#pragma omp for schedule(dynamic, 4)
+      for (int ti = 0; ti < T; ti++) {
+        const Tile &t = tiles[ti];
+        touched.clear();
+        for (int i = t.row0; i < t.row0 + t.nown; i++)
+          for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+            const int c = colind[j];
+            if (c < t.row0 && c >= rb && c < i) {
+              if (uses[c]++ == 0) touched.push_back(c);
+            }
+          }
+        for (int i = t.row0; i < t.row0 + t.nown; i++)
+          for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+            const int c = colind[j];
+            if (c < t.row0 && c >= rb && c < i && uses[c] <= thr) {
+              __atomic_fetch_or(&farbits[(size_t)j >> 6], 1ull << (j & 63), __ATOMIC_RELAXED);
+              marked++;
+            }
+          }
+        for (int c : touched) uses[c] = 0;
+      }
+    }
+    P.far_candidates = marked;
+    if (marked == 0) farbits.clear();
+  }
+
+  // ---- HYB, second half: after a cut ------------------------------------------------------
+  // A marked entry whose two rows ended up in one tile is an ordinary entry again.
+  // farL / farU = far entries of a row as the lower / the mirrored (upper) end.
+  void resolve_far(const std::vector<Tile> &tiles) {
+    tile_of_row.assign(rows, 0);
+    const int T = (int)tiles.size();
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+    for (int ti = 0; ti < T; ti++)
+      for (int r = 0; r < tiles[ti].nown; r++) tile_of_row[tiles[ti].row0 - rb + r] = ti;
+    farL.assign(rows, 0);
+    farU.assign(rows, 0);
+    P.far_entries = 0;
+    if (farbits.empty()) return;
+    int64_t kept = 0;
+#pragma omp parallel for schedule(static) reduction(+ : kept) num_threads(host_threads())
+    for (int i = rb; i < re; i++)
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        if (!is_far(j)) continue;
+        const int c = colind[j];
+        if (tile_of_row[c - rb] == tile_of_row[i - rb]) {
+          __atomic_fetch_and(&farbits[(size_t)j >> 6], ~(1ull << (j & 63)), __ATOMIC_RELAXED);
+          continue;
+        }
+        farL[i - rb]++;
+        __atomic_fetch_add(&farU[c - rb], 1, __ATOMIC_RELAXED);
+        kept++;
+      }
+    P.far_entries = kept;
+    if (kept == 0) farbits.clear();
   }
 
   // ---- virtual rows: one lane each ----------------------------------------------
@@ -484,10 +653,7 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
   // their partial sums to the same LDS slot and only the first carries the
   // diagonal.  Virtual rows are sorted by packet count (stable counting sort,
   // descending): the lanes still active in packet g of a slice are a prefix.
-  struct VRow {
-    int32_t r, k0, a; // local row, first packet of the chunk, packets in the chunk
-  };
-  auto build_vrows = [&](const Tile &t, std::vector<VRow> &vr) {
+  void build_vrows(const Tile &t, std::vector<VRow> &vr) const {
     vr.clear();
     int64_t sum = 0;
     for (int r = 0; r < t.nown; r++) sum += lcnt[t.row0 - rb + r] >> 2;
@@ -549,10 +715,30 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
       std::stable_sort(vr.begin() + p0, vr.begin() + p1,
                        [](const VRow &x, const VRow &y) { return x.a > y.a; });
     }
-  };
-  std::vector<int64_t> tile_len(T, 0);
-  {
-    std::vector<int32_t> nv(T, 0);
+  }
+
+  // `cnt` near columns of row i from its k0-th on, stored order
+  void near_cols(int i, int k0, int cnt, std::vector<int32_t> &out) const {
+    out.clear();
+    int seen = 0;
+    for (int j = rowptr[i]; j < rowptr[i + 1] && (int)out.size() < cnt; j++)
+      if (near(i, j)) {
+        if (seen >= k0) out.push_back(colind[j]);
+        seen++;
+      }
+  }
+
+  // ---- per tile: virtual rows, slices, leaders; then all offsets ---------------------------
+  // Multi-dof FEM matrices repeat themselves: the rows of one mesh node have
+  // (nearly) the same columns.  A lane whose packet-covered column sequence is
+  // a PREFIX of the sequence of an earlier lane of its slice (earlier = at
+  // least as many packets) does not store slots at all: it reads the slots of
+  // that LEADER lane (same addresses -> the same cache lines serve the run).
+  // Per slice: a 64-bit leader mask, and one byte per lane naming its leader.
+  bool size_streams() {
+    const int T = (int)P.tiles.size();
+    tile_len.assign(T, 0);
+    tile_slen.assign(T, 0);
 #pragma omp parallel num_threads(host_threads())
     {
       std::vector<VRow> vr;
@@ -560,31 +746,40 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
       for (int ti = 0; ti < T; ti++) {
         Tile &t = P.tiles[ti];
         build_vrows(t, vr);
-        nv[ti] = (int32_t)vr.size();
-        t.nvrows = nv[ti];
-        t.nslices = (nv[ti] + kLanes - 1) / kLanes;
-        int64_t left = 0;
-        for (int r = 0; r < t.nown; r++) left += lcnt[t.row0 - rb + r] & 3;
+        t.nvrows = (int32_t)vr.size();
+        t.nslices = (t.nvrows + kLanes - 1) / kLanes;
+        int64_t left = 0, far = 0, farlow = 0;
+        for (int r = 0; r < t.nown; r++) {
+          left += lcnt[t.row0 - rb + r] & 3;
+          if (!farbits.empty()) {
+            farlow += farL[t.row0 - rb + r];
+            far += farL[t.row0 - rb + r] + farU[t.row0 - rb + r];
+          }
+        }
         t.ncoo = (int32_t)left;
+        t.nfar = (int32_t)far;
+        t.nfar_low = (int32_t)farlow;
       }
     }
-    // ---- offsets -------------------------------------------------------------
-    int64_t halo = 0, slices = 0, nsl = 0, nvr = 0;
+    int64_t halo = 0, slices = 0, nsl = 0, nvr = 0, far = 0;
     for (auto &t : P.tiles) {
       t.halo_off = (int32_t)halo;
       t.slice_base = (int32_t)slices;
       t.slot_off = (int32_t)nsl;
       t.vrow_off = (int32_t)nvr;
+      t.far_off = (int32_t)far;
       halo += t.nslots - t.nown;
       nsl += t.nslots;
       slices += t.nslices;
       nvr += t.nvrows;
-      if (halo > 0x7fffffffLL || nsl > 0x7ffffff0LL || nvr > 0x7ffffff0LL) {
+      far += align_up(t.nfar, 256);
+      if (halo > 0x7fffffffLL || nsl > 0x7ffffff0LL || nvr > 0x7ffffff0LL || far > 0x7fffff00LL) {
         P.error = "halo index overflow";
         return false;
       }
     }
     P.nhalo = halo;
+    P.far_len = far;
     P.halo_col.assign((size_t)halo + 1, 0);
     P.slot_col.assign((size_t)nsl + 1, 0); // +1: the kernel's clamped dummy read
     P.slice_meta.assign((size_t)slices, SliceMeta{0u, 0u, 0ull});
@@ -592,80 +787,60 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     P.rowinfo.assign((size_t)nvr + 1, 0);
     P.diag.assign((size_t)nvr + 1, V(0));
     P.nvrows = nvr;
-  }
-
-  // ---- per tile: stream sizes, then fill ------------------------------------------
-  // Multi-dof FEM matrices repeat themselves: the rows of one mesh node have
-  // (nearly) the same columns.  A lane whose packet-covered column sequence is
-  // a PREFIX of the sequence of an earlier lane of its slice (earlier = at
-  // least as many packets) does not store slots at all: it reads the slots of
-  // that LEADER lane (same addresses -> the same cache lines serve the run).
-  // Per slice: a 64-bit leader mask, and one byte per lane naming its leader.
-  std::vector<int64_t> tile_slen(T, 0);
-  auto lower_cols = [&](int i, int k0, int cnt, std::vector<int32_t> &out) {
-    out.clear();
-    int seen = 0;
-    for (int j = rowptr[i]; j < rowptr[i + 1] && (int)out.size() < cnt; j++)
-      if (stored(i, colind[j])) {
-        if (seen >= k0) out.push_back(colind[j]);
-        seen++;
-      }
-  };
 #pragma omp parallel num_threads(host_threads())
-  {
-    std::vector<VRow> vr;
-    std::vector<int32_t> cur;
-    std::vector<std::vector<int32_t>> lseq(kLanes); // sequences of the slice's leaders
+    {
+      std::vector<VRow> vr;
+      std::vector<int32_t> cur;
+      std::vector<std::vector<int32_t>> lseq(kLanes); // sequences of the slice's leaders
 #pragma omp for schedule(dynamic, 1)
-    for (int ti = 0; ti < T; ti++) {
-      Tile &t = P.tiles[ti];
-      build_vrows(t, vr);
-      int64_t off = 0, soff = 0;
-      for (int s = 0; s < t.nslices; s++) {
-        off = align_up(off, kAlignEntries);
-        soff = align_up(soff, 4);
-        int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nvrows);
-        uint32_t cnt0 = 0;
-        uint64_t leaders = 0;
-        SliceMeta &sm = P.slice_meta[t.slice_base + s];
-        sm.voff = (uint32_t)off;
-        if (soff >= (1 << 25)) tile_slen[ti] = -1; // flagged below
-        sm.soff_cnt0 = (uint32_t)soff;
-        uint8_t *ll = P.leadlane.data() + (size_t)(t.slice_base + s) * kLanes;
-        for (int p = p0; p < p1; p++) {
-          const VRow &v = vr[p];
-          const int l = p - p0;
-          off += (int64_t)v.a * 4;
-          if (v.a >= 1) cnt0++;
-          int lead = l;
-          if (v.a >= 1) {
-            lower_cols(t.row0 + v.r, v.k0 * 4, v.a * 4, cur);
-            // latest leaders first: siblings sit next to each other
-            for (int j = l - 1; j >= 0 && lead == l; j--)
-              if (((leaders >> j) & 1) && lseq[j].size() >= cur.size() && !lseq[j].empty() &&
-                  lseq[j][0] == cur[0] && std::equal(cur.begin(), cur.end(), lseq[j].begin()))
-                lead = j;
+      for (int ti = 0; ti < T; ti++) {
+        Tile &t = P.tiles[ti];
+        build_vrows(t, vr);
+        int64_t off = 0, soff = 0;
+        for (int s = 0; s < t.nslices; s++) {
+          off = align_up(off, kAlignEntries);
+          soff = align_up(soff, 4);
+          int p0 = s * kLanes, p1 = std::min(p0 + kLanes, (int)t.nvrows);
+          uint32_t cnt0 = 0;
+          uint64_t leaders = 0;
+          SliceMeta &sm = P.slice_meta[t.slice_base + s];
+          sm.voff = (uint32_t)off;
+          if (soff >= (1 << 25)) tile_slen[ti] = -1; // flagged below
+          sm.soff_cnt0 = (uint32_t)soff;
+          uint8_t *ll = P.leadlane.data() + (size_t)(t.slice_base + s) * kLanes;
+          for (int p = p0; p < p1; p++) {
+            const VRow &v = vr[p];
+            const int l = p - p0;
+            off += (int64_t)v.a * 4;
+            if (v.a >= 1) cnt0++;
+            int lead = l;
+            if (v.a >= 1) {
+              near_cols(t.row0 + v.r, v.k0 * 4, v.a * 4, cur);
+              // latest leaders first: siblings sit next to each other
+              for (int j = l - 1; j >= 0 && lead == l; j--)
+                if (((leaders >> j) & 1) && lseq[j].size() >= cur.size() && !lseq[j].empty() &&
+                    lseq[j][0] == cur[0] && std::equal(cur.begin(), cur.end(), lseq[j].begin()))
+                  lead = j;
+            }
+            ll[l] = (uint8_t)lead;
+            if (lead == l) {
+              leaders |= 1ull << l;
+              soff += (int64_t)v.a * 4;
+              if (v.a >= 1) lseq[l].swap(cur);
+              else lseq[l].clear();
+            }
           }
-          ll[l] = (uint8_t)lead;
-          if (lead == l) {
+          for (int l = p1 - p0; l < kLanes; l++) { // unused lanes: own (empty) runs
             leaders |= 1ull << l;
-            soff += (int64_t)v.a * 4;
-            if (v.a >= 1) lseq[l].swap(cur);
-            else lseq[l].clear();
+            ll[l] = (uint8_t)l;
           }
+          sm.soff_cnt0 |= cnt0 << 25;
+          sm.leaders = leaders;
         }
-        for (int l = p1 - p0; l < kLanes; l++) { // unused lanes: own (empty) runs
-          leaders |= 1ull << l;
-          ll[l] = (uint8_t)l;
-        }
-        sm.soff_cnt0 |= cnt0 << 25;
-        sm.leaders = leaders;
+        tile_len[ti] = align_up(off, kAlignEntries);
+        if (tile_slen[ti] >= 0) tile_slen[ti] = align_up(soff, kAlignEntries);
       }
-      tile_len[ti] = align_up(off, kAlignEntries);
-      if (tile_slen[ti] >= 0) tile_slen[ti] = align_up(soff, kAlignEntries);
     }
-  }
-  {
     int64_t off = 0, soff = 0, coo = 0;
     for (int ti = 0; ti < T; ti++) {
       if (tile_slen[ti] < 0) {
@@ -694,143 +869,204 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
     P.cvals.assign((size_t)coo + 256, V(0));
     P.crows.assign((size_t)coo + 256, 0);
     P.ccols.assign((size_t)coo + 256, 0);
+    P.fvals.assign((size_t)P.far_len + 256, V(0));
+    P.frows.assign((size_t)P.far_len + 256, 0);
+    P.fcols.assign((size_t)P.far_len + 256, 0);
+    return true;
   }
-  pt.lap("core: vrows + sizes");
-  bool dup_error = false;
-  P.tile_rounds.assign(T, 0);
-#pragma omp parallel num_threads(host_threads())
-  {
-    std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
-    std::vector<int32_t> hcols, lowj;
-    std::vector<VRow> vr;
-#pragma omp for schedule(dynamic, 1)
-    for (int ti = 0; ti < T; ti++) {
-      const Tile &t = P.tiles[ti];
-      // halo: unique stored columns outside the tile; in-block columns (they get
-      // a y window entry and a strip entry) first, then the off-block columns of
-      // a mirrored shard (x only), each class ascending
-      hcols.clear();
-      for (int r = 0; r < t.nown; r++) {
-        int i = t.row0 + r;
+
+  // ---- fill: halo slot tables, packet streams, COO leftovers, far sections -------------
+  bool fill_streams() {
+    const int T = (int)P.tiles.size();
+    P.tile_rounds.assign(T, 0);
+    struct FarE {
+      int32_t r, c; // own local row, ORIGINAL global column
+      V v;
+    };
+    // the mirrored (upper) ends of the far entries are found from the lower side:
+    // a cursor per tile, filled in parallel, sorted afterwards for a fixed order
+    std::vector<std::vector<FarE>> far_up(farbits.empty() ? 0 : T);
+    if (!farbits.empty()) {
+      std::vector<int32_t> cur(T, 0);
+      for (int ti = 0; ti < T; ti++)
+        far_up[ti].resize((size_t)(P.tiles[ti].nfar - P.tiles[ti].nfar_low));
+#pragma omp parallel for schedule(dynamic, 256) num_threads(host_threads())
+      for (int i = rb; i < re; i++)
         for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-          int c = colind[j];
-          if (stored(i, c) && (c < t.row0 || c >= re) && colmap[c] < 0) {
-            colmap[c] = 0;
-            hcols.push_back(c);
-          }
+          if (!is_far(j)) continue;
+          const int c = colind[j], tc = tile_of_row[c - rb];
+          const int at = __atomic_fetch_add(&cur[tc], 1, __ATOMIC_RELAXED);
+          far_up[tc][at] = FarE{c - P.tiles[tc].row0, orig(i), values[j]};
         }
-      }
-      auto offblock = [&](int c) { return mirror && (c < rb || c >= re); };
-      std::sort(hcols.begin(), hcols.end(), [&](int a, int b) {
-        const bool oa = offblock(a), ob = offblock(b);
-        return oa != ob ? ob : a < b;
-      });
-      if ((int)hcols.size() != t.nslots - t.nown) {
-#pragma omp atomic write
-        dup_error = true;
-      }
-      {
-        int ny = t.nown;
-        for (int c : hcols)
-          if (!offblock(c)) ny++;
-        P.tiles[ti].ny = ny;
-      }
-      for (size_t h = 0; h < hcols.size(); h++) {
-        colmap[hcols[h]] = t.nown + (int)h;
-        P.halo_col[t.halo_off + h] = hcols[h];
-      }
-      auto slot_of = [&](int c) {
-        return (uint16_t)((c >= t.row0 && c < re) ? c - t.row0 : colmap[c]);
-      };
-      // positions (in the CSR) of the lower entries of local row r, in stored
-      // order -- works whether or not the columns of a row ascend
-      auto lower_of = [&](int r, std::vector<int32_t> &out) {
-        out.clear();
-        int i = t.row0 + r;
-        for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
-          if (stored(i, colind[j])) out.push_back(j);
-      };
-      build_vrows(t, vr);
-      V *tv = P.vals.data() + t.nnz_off;
-      uint16_t *ts = P.slots.data() + t.sl_off;
-      std::vector<std::vector<int32_t>> low(kLanes);
-      for (int s = 0; s < t.nslices; s++) {
-        int p0 = s * kLanes, m = std::min(kLanes, (int)t.nvrows - p0);
-        int amax = 0;
-        for (int l = 0; l < m; l++) {
-          const VRow &v = vr[p0 + l];
-          const int i = t.row0 + v.r;
-          lower_of(v.r, low[l]);
-          amax = std::max(amax, v.a);
-          P.rowinfo[t.vrow_off + p0 + l] = (uint32_t)v.r | ((uint32_t)v.a << 16);
-          V d = V(0);
-          if (v.k0 == 0)
-            for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
-              if (colind[j] == i) d = values[j]; // last duplicate wins, like :1292
-          P.diag[t.vrow_off + p0 + l] = d;
-        }
-        const SliceMeta &sm = P.slice_meta[t.slice_base + s];
-        int64_t o = sm.voff, os = sm.soff_cnt0 & 0x1ffffff;
-        P.tile_rounds[ti] += amax;
-        for (int g = 0; g < amax; g++) {
-          int cnt = 0;
-          while (cnt < m && vr[p0 + cnt].a > g) cnt++;
-          int lead = -1; // index of lane l's leader among the leaders of this packet
-          for (int l = 0; l < cnt; l++) {
-            const bool is_leader = (sm.leaders >> l) & 1;
-            if (is_leader) lead++;
-            for (int j = 0; j < kPacket; j++) {
-              int q = low[l][(vr[p0 + l].k0 + g) * kPacket + j];
-              tv[o + packet_val_pos<V>(l, j, cnt)] = val_at(t.row0 + vr[p0 + l].r, q);
-              if (is_leader) ts[os + packet_slot_pos(lead, j)] = slot_of(colind[q]);
+    }
+#pragma omp parallel num_threads(host_threads())
+    {
+      std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
+      std::vector<int32_t> hcols, lowj;
+      std::vector<VRow> vr;
+      std::vector<FarE> fl;
+#pragma omp for schedule(dynamic, 1)
+      for (int ti = 0; ti < T; ti++) {
+        const Tile &t = P.tiles[ti];
+        // halo: unique near columns outside the tile; in-block columns (they get
+        // a y window entry and a strip entry) first, then the off-block columns of
+        // a mirrored shard (x only), each class ascending
+        hcols.clear();
+        for (int r = 0; r < t.nown; r++) {
+          const int i = t.row0 + r;
+          for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+            const int c = colind[j];
+            if (near(i, j) && (c < t.row0 || c >= re) && colmap[c] < 0) {
+              colmap[c] = 0;
+              hcols.push_back(c);
             }
           }
-          o += 4 * (int64_t)cnt;
-          os += 4 * (int64_t)(lead + 1);
         }
-      }
-      // COO leftovers: the last len%4 lower entries of every row, natural row
-      // order, in 256-entry packets with the packet value layout
-      {
-        V *cv = P.cvals.data() + t.coo_off;
-        uint16_t *cr = P.crows.data() + t.coo_off, *cc = P.ccols.data() + t.coo_off;
-        int64_t e = 0;
-        for (int r = 0; r < t.nown; r++) {
-          lower_of(r, lowj);
-          int len = (int)lowj.size();
-          for (int k = (len >> 2) << 2; k < len; k++) {
-            int q = lowj[k];
-            int64_t pk = e >> 8;
-            int l = (int)((e & 255) >> 2), j = (int)(e & 3);
-            cv[pk * 256 + packet_val_pos<V>(l, j)] = val_at(t.row0 + r, q);
-            cr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)r;
-            cc[pk * 256 + packet_slot_pos(l, j)] = slot_of(colind[q]);
-            e++;
+        auto offblock = [&](int c) { return mirror && (c < rb || c >= re); };
+        std::sort(hcols.begin(), hcols.end(), [&](int a, int b) {
+          const bool oa = offblock(a), ob = offblock(b);
+          return oa != ob ? ob : a < b;
+        });
+        bool bad = (int)hcols.size() != t.nslots - t.nown;
+        {
+          int ny = t.nown;
+          for (int c : hcols)
+            if (!offblock(c)) ny++;
+          P.tiles[ti].ny = ny;
+        }
+        for (size_t h = 0; h < hcols.size(); h++) {
+          colmap[hcols[h]] = t.nown + (int)h;
+          if (!bad) P.halo_col[t.halo_off + h] = hcols[h];
+        }
+        auto slot_of = [&](int c) {
+          return (uint16_t)((c >= t.row0 && c < re) ? c - t.row0 : colmap[c]);
+        };
+        // positions (in the CSR) of the near entries of local row r, in stored
+        // order -- works whether or not the columns of a row ascend
+        auto lower_of = [&](int r, std::vector<int32_t> &out) {
+          out.clear();
+          const int i = t.row0 + r;
+          for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+            if (near(i, j)) out.push_back(j);
+        };
+        build_vrows(t, vr);
+        V *tv = P.vals.data() + t.nnz_off;
+        uint16_t *ts = P.slots.data() + t.sl_off;
+        std::vector<std::vector<int32_t>> low(kLanes);
+        double amax_t = 0.0; // largest |value| of the tile
+        for (int s = 0; s < t.nslices && !bad; s++) {
+          int p0 = s * kLanes, m = std::min(kLanes, (int)t.nvrows - p0);
+          int amax = 0;
+          for (int l = 0; l < m; l++) {
+            const VRow &v = vr[p0 + l];
+            const int i = t.row0 + v.r;
+            lower_of(v.r, low[l]);
+            amax = std::max(amax, v.a);
+            P.rowinfo[t.vrow_off + p0 + l] = (uint32_t)v.r | ((uint32_t)v.a << 16);
+            V d = V(0);
+            if (v.k0 == 0)
+              for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+                if (colind[j] == i) d = values[j]; // last duplicate wins, like :1292
+            P.diag[t.vrow_off + p0 + l] = d;
+            amax_t = std::max(amax_t, std::fabs((double)d));
+          }
+          const SliceMeta &sm = P.slice_meta[t.slice_base + s];
+          int64_t o = sm.voff, os = sm.soff_cnt0 & 0x1ffffff;
+          P.tile_rounds[ti] += amax;
+          for (int g = 0; g < amax; g++) {
+            int cnt = 0;
+            while (cnt < m && vr[p0 + cnt].a > g) cnt++;
+            int lead = -1; // index of lane l's leader among the leaders of this packet
+            for (int l = 0; l < cnt; l++) {
+              const bool is_leader = (sm.leaders >> l) & 1;
+              if (is_leader) lead++;
+              for (int j = 0; j < kPacket; j++) {
+                int q = low[l][(vr[p0 + l].k0 + g) * kPacket + j];
+                const V av = val_at(t.row0 + vr[p0 + l].r, q);
+                tv[o + packet_val_pos<V>(l, j, cnt)] = av;
+                amax_t = std::max(amax_t, std::fabs((double)av));
+                if (is_leader) ts[os + packet_slot_pos(lead, j)] = slot_of(colind[q]);
+              }
+            }
+            o += 4 * (int64_t)cnt;
+            os += 4 * (int64_t)(lead + 1);
           }
         }
-        if (e != t.ncoo) {
+        // COO leftovers: the last len%4 near entries of every row, natural row
+        // order, in 256-entry packets with the packet value layout
+        if (!bad) {
+          V *cv = P.cvals.data() + t.coo_off;
+          uint16_t *cr = P.crows.data() + t.coo_off, *cc = P.ccols.data() + t.coo_off;
+          int64_t e = 0;
+          for (int r = 0; r < t.nown; r++) {
+            lower_of(r, lowj);
+            int len = (int)lowj.size();
+            for (int k = (len >> 2) << 2; k < len && e < t.ncoo; k++) {
+              int q = lowj[k];
+              int64_t pk = e >> 8;
+              int l = (int)((e & 255) >> 2), j = (int)(e & 3);
+              const V av = val_at(t.row0 + r, q);
+              cv[pk * 256 + packet_val_pos<V>(l, j)] = av;
+              amax_t = std::max(amax_t, std::fabs((double)av));
+              cr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)r;
+              cc[pk * 256 + packet_slot_pos(l, j)] = slot_of(colind[q]);
+              e++;
+            }
+          }
+          if (e != t.ncoo) bad = true;
+        }
+        // FAR section: own rows' far entries in row order, then the mirror images of
+        // other tiles' far entries that end in this tile's rows (sorted: fixed order)
+        if (t.nfar > 0 && !bad) {
+          fl.clear();
+          for (int r = 0; r < t.nown; r++) {
+            const int i = t.row0 + r;
+            for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+              if (is_far(j)) fl.push_back(FarE{r, orig(colind[j]), values[j]});
+          }
+          if ((int)fl.size() != t.nfar_low) bad = true;
+          std::vector<FarE> &up = far_up[ti];
+          std::sort(up.begin(), up.end(), [](const FarE &a, const FarE &b) {
+            return a.r != b.r ? a.r < b.r : a.c < b.c;
+          });
+          fl.insert(fl.end(), up.begin(), up.end());
+          if ((int)fl.size() != t.nfar) bad = true;
+          V *fv = P.fvals.data() + t.far_off;
+          uint16_t *fr = P.frows.data() + t.far_off;
+          int32_t *fc = P.fcols.data() + t.far_off;
+          for (size_t e = 0; e < fl.size() && (int64_t)e < t.nfar; e++) {
+            const int64_t pk = (int64_t)e >> 8;
+            const int l = (int)((e & 255) >> 2), j = (int)(e & 3);
+            fv[pk * 256 + packet_val_pos<V>(l, j)] = fl[e].v;
+            amax_t = std::max(amax_t, std::fabs((double)fl[e].v));
+            fr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)fl[e].r;
+            fc[pk * 256 + packet_slot_pos(l, j)] = fl[e].c;
+          }
+        }
+        P.tiles[ti].aexp = (amax_t > 0.0 && std::isfinite(amax_t)) ? std::ilogb(amax_t) + 1 : -1000;
+        if (bad) {
 #pragma omp atomic write
           dup_error = true;
         }
+        for (int c : hcols) colmap[c] = -1;
       }
-      for (int c : hcols) colmap[c] = -1;
     }
-  }
-  if (dup_error) {
-    P.error = "internal: halo / leftover count mismatch";
-    return false;
-  }
-  if (mirror_fail) {
-    P.error = "mirror: structurally unsymmetric off-block entries";
-    return false;
+    if (dup_error) {
+      P.error = "internal: halo / leftover / far count mismatch";
+      return false;
+    }
+    if (mirror_fail) {
+      P.error = "mirror: structurally unsymmetric off-block entries";
+      return false;
+    }
+    if (getenv("CFS_PLAN_VERBOSE"))
+      fprintf(stderr, "[cfs_plan] slot stream %lld entries for %lld value entries; far entries %lld (stored twice)\n",
+              (long long)P.slot_len, (long long)P.stream_len, (long long)P.far_entries);
+    return true;
   }
 
-  pt.lap("core: fill streams");
-  if (getenv("CFS_PLAN_VERBOSE"))
-    fprintf(stderr, "[cfs_plan] slot stream %lld entries for %lld value entries\n",
-            (long long)P.slot_len, (long long)P.stream_len);
   // ---- halo fold index: strips -> destination rows, fixed order --------------
-  {
+  void fold_index() {
     const int64_t H = P.nhalo;
     std::vector<int32_t> lcount(rows + 1, 0), rcount(rb + 1, 0);
     for (int64_t q = 0; q < H; q++) {
@@ -870,48 +1106,98 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
                         P.row_splits.begin()) - 1;
       P.send_counts[owner]++;
     }
+    if (getenv("CFS_PLAN_VERBOSE")) {
+      int64_t mx = 0, long8 = 0, sum_long = 0;
+      for (size_t i = 0; i + 1 < P.fold_ptr.size(); i++) {
+        int64_t l = P.fold_ptr[i + 1] - P.fold_ptr[i];
+        mx = std::max(mx, l);
+        if (l > 8) {
+          long8++;
+          sum_long += l - 8;
+        }
+      }
+      fprintf(stderr, "[cfs_plan] fold: %zu destinations, longest list %lld, %lld lists > 8 (%lld entries beyond)\n",
+              P.fold_row.size(), (long long)mx, (long long)long8, (long long)sum_long);
+    }
   }
 
-  pt.lap("core: fold index");
-  if (getenv("CFS_PLAN_VERBOSE")) {
-    int64_t mx = 0, long8 = 0, sum_long = 0;
-    for (size_t i = 0; i + 1 < P.fold_ptr.size(); i++) {
-      int64_t l = P.fold_ptr[i + 1] - P.fold_ptr[i];
-      mx = std::max(mx, l);
-      if (l > 8) {
-        long8++;
-        sum_long += l - 8;
-      }
-    }
-    fprintf(stderr, "[cfs_plan] fold: %zu destinations, longest list %lld, %lld lists > 8 (%lld entries beyond)\n",
-            P.fold_row.size(), (long long)mx, (long long)long8, (long long)sum_long);
-  }
-  // ---- LDS window: the largest tile decides --------------------------------
-  {
+  // ---- LDS window, per-chunk first tiles, schedule space -> original indices -------------
+  void finish() {
     int lds_slots = 64;
     for (auto &t : P.tiles) lds_slots = std::max(lds_slots, (int)t.nslots);
     P.lds_slots = (lds_slots + 63) / 64 * 64;
-  }
-
-  P.group_first.assign(P.ngroups, Tile{});
-  for (int g = 0; g < P.ngroups; g++)
-    if (P.group_ptr[g] < P.group_ptr[g + 1]) P.group_first[g] = P.tiles[P.group_ptr[g]];
-
-  // ---- schedule space -> original indices -------------------------------------
-  // the kernels address x and y in the caller's (original) numbering
-  {
-    auto orig = [&](int c) { return (perm_in && c >= rb && c < re) ? (*perm_in)[c - rb] : c; };
+    const int nc = L.nchunks();
+    P.group_first.assign(nc, Tile{});
+    for (int g = 0; g < nc; g++)
+      if (P.group_ptr[g] < P.group_ptr[g + 1]) P.group_first[g] = P.tiles[P.group_ptr[g]];
+    // the kernels address x and y in the caller's (original) numbering
     for (const Tile &t : P.tiles) {
       for (int i = 0; i < t.nown; i++) P.slot_col[t.slot_off + i] = orig(t.row0 + i);
       for (int h = 0; h < t.nslots - t.nown; h++)
         P.slot_col[t.slot_off + t.nown + h] = orig(P.halo_col[t.halo_off + h]);
     }
     P.fold_dst.resize(P.fold_row.size());
-    for (size_t i = 0; i < P.fold_row.size(); i++)
-      P.fold_dst[i] = orig(P.fold_row[i] + rb) - rb;
+    for (size_t i = 0; i < P.fold_row.size(); i++) P.fold_dst[i] = orig(P.fold_row[i] + rb) - rb;
     if (perm_in) P.perm = *perm_in;
   }
-  return true;
+
+  // the whole build; cut_only: the caller only wants to compare halo sizes of two row orders
+  bool run(const int *row_splits_in, bool cut_only) {
+    if (!setup(row_splits_in)) return false;
+    if (!count_rows()) return false;
+    pt.lap("core: row counts");
+    cut_chunks();
+    if (opt.hyb && rows > 0) {
+      std::vector<Tile> t1;
+      std::vector<int32_t> gp1;
+      if (!cut_tiles(t1, gp1)) return false;
+      mark_far(t1);
+      pt.lap("core: far marks");
+    }
+    if (!cut_tiles(P.tiles, P.group_ptr)) return false;
+    if (!opt.hyb && opt.count_far && rows > 0 && !cut_only) { // what would HYB take out? (tune())
+      mark_far(P.tiles);
+      farbits.clear();
+    }
+    resolve_far(P.tiles);
+    if (!farbits.empty()) {
+      // the far entries are known now: near counts, costs and -- in natural order -- the
+      // chunk boundaries once more, then the final tiles.  A marked entry stays far
+      // exactly when its rows are in different tiles of THE FINAL cut (entries that
+      // became local are near again, which can only lower the slot demand of a tile).
+      if (!count_rows()) return false;
+      cut_chunks();
+      if (!cut_tiles(P.tiles, P.group_ptr)) return false;
+      resolve_far(P.tiles);
+      if (!count_rows()) return false;
+    }
+    pt.lap("core: cut tiles");
+    if (cut_only) {
+      P.nhalo = 0;
+      for (const Tile &t : P.tiles) P.nhalo += t.nslots - t.nown;
+      return true;
+    }
+    if (!size_streams()) return false;
+    pt.lap("core: vrows + sizes");
+    if (!fill_streams()) return false;
+    pt.lap("core: fill streams");
+    fold_index();
+    pt.lap("core: fold index");
+    finish();
+    return true;
+  }
+};
+
+// Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the CSR
+// (natural order: the caller's full CSR; clustered: its lower triangle in schedule
+// space).  Returns false (plan.error set) when the matrix cannot be scheduled.
+template <typename V>
+bool build_plan_core(int n, const int *rowptr, const int *colind, const V *values,
+                     int nranks, int rank, const int *row_splits_in,
+                     const Options &opt, const std::vector<int32_t> *chunks_in,
+                     const std::vector<int32_t> *perm_in, SymPlan<V> &P, bool cut_only = false) {
+  Builder<V> b(n, rowptr, colind, values, nranks, rank, opt, chunks_in, perm_in, P);
+  return b.run(row_splits_in, cut_only);
 }
 
 // Greedy graph growing: order the rows [rb, re) so that `ngroups` consecutive
@@ -1010,7 +1296,7 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
 // one's, consecutive in the sweep order).
 template <typename V> struct ScheduleSpace {
   bool valid = false;
-  int rb = 0, re = 0, ngroups = 0;
+  int rb = 0, re = 0, nchunks = 0;
   std::vector<int32_t> perm, chunk, brp, bci;
   std::vector<V> bva;
 };
@@ -1045,34 +1331,24 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
       return false;
     }
   }
-  if (!opt.reorder || opt.force_order == 1 || rb < 0 || re > n || rows < 256)
+  const int block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
+  if (!opt.reorder || opt.force_order == 1 || rb < 0 || re > n || rows < 256 ||
+      (block != 256 && block != 512 && block != 1024)) // (the core reports a bad block)
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
                               nullptr, nullptr, P);
-  // number of persistent groups: same rule as the core
-  int block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
-  int max_slots = opt.max_slots > 0 ? opt.max_slots : kDefaultSlots;
-  const int slot_bytes = (int)sizeof(V) + 8;
-  max_slots = std::min(max_slots, std::min((160 * 1024 - 64) / slot_bytes, kSlotsPerThread * block));
-  max_slots = std::max(max_slots, 64);
-  int wg_per_cu = (int)std::min<int64_t>(160 * 1024 / ((int64_t)((max_slots + 63) / 64 * 64) * slot_bytes + kStaticLds),
-                                         (4 * 4 * 64) / std::max(block, 64));
-  if (opt.wg_per_cu > 0) wg_per_cu = opt.wg_per_cu;
-  if (wg_per_cu < 1) wg_per_cu = 1;
-  const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
-  int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
-  int by_rows = ((rows + min_rows_per_group() - 1) / min_rows_per_group() + 7) / 8 * 8;
-  if (ngroups > by_rows) ngroups = by_rows;
-  if (ngroups < 8) ngroups = 8;
+  // the launch layout: same rule as the core
+  const ChunkLayout L = chunk_layout<V>(rows, opt);
+  const int nchunks = L.nchunks();
 
   PhaseTimer pt;
   const bool mirror = opt.mirror_offblock && nranks > 1;
   ScheduleSpace<V> local;
   ScheduleSpace<V> &sp = cache ? *cache : local;
-  if (cache && cache->valid && cache->rb == rb && cache->re == re && cache->ngroups == 2 * ngroups &&
+  if (cache && cache->valid && cache->rb == rb && cache->re == re && cache->nchunks == 2 * nchunks &&
       opt.group_share.empty()) {
     // reuse: same row order, every second cluster boundary; always clustered
-    std::vector<int32_t> merged(ngroups + 1);
-    for (int g = 0; g <= ngroups; g++) merged[g] = sp.chunk[2 * g];
+    std::vector<int32_t> merged(nchunks + 1);
+    for (int g = 0; g <= nchunks; g++) merged[g] = sp.chunk[2 * g];
     pt.lap("schedule space reused");
     if (build_plan_core<V>(n, sp.brp.data(), sp.bci.data(), sp.bva.data(), nranks, rank,
                            row_splits_in, opt, &merged, &sp.perm, P))
@@ -1082,7 +1358,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   }
   sp.valid = false;
   std::vector<int32_t> &perm = sp.perm, &chunk = sp.chunk;
-  cluster_rows<V>(n, rowptr, colind, rb, re, ngroups, opt.group_share, perm, chunk, mirror);
+  cluster_rows<V>(n, rowptr, colind, rb, re, nchunks, L.shares(opt), perm, chunk, mirror);
   pt.lap("cluster_rows");
   std::vector<int32_t> inv(rows);
   for (int p = 0; p < rows; p++) inv[perm[p] - rb] = rb + p;
@@ -1118,6 +1394,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     brp[p + 1] = cnt;
   }
   for (int p = rb; p < re; p++) brp[p + 1] += brp[p]; // rows < rb are empty
+  for (int p = re + 1; p <= n + 1; p++) brp[p] = brp[re]; // rows >= re too (brp[n] = nnz)
   const int64_t bnnz = brp[re];
   std::vector<int32_t> &bci = sp.bci;
   std::vector<V> &bva = sp.bva;
@@ -1188,7 +1465,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   // pwtk stand-in 2.1x fewer -> 11 % slower; random sparsity has no locality to
   // find).  In fp32 the scattered 4-byte accesses weigh twice as much against a
   // stream half as long: the same 3.5x is 7 % slower, so the bar is 6x there.
-  // Only the tile cut of both orders is needed to decide.
+  // Only the tile cut of both orders is needed to decide (with HYB: the halo that is
+  // left once the far entries are gone).
   bool use_clustered = true;
   if (opt.force_order != 2) {
     SymPlan<V> C, N;
@@ -1197,8 +1475,9 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     const bool n_ok = build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in,
                                          opt, nullptr, nullptr, N, true);
     if (getenv("CFS_PLAN_VERBOSE"))
-      fprintf(stderr, "[cfs_plan] halo slots: clustered %lld, natural %lld\n",
-              c_ok ? (long long)C.nhalo : -1LL, n_ok ? (long long)N.nhalo : -1LL);
+      fprintf(stderr, "[cfs_plan] halo slots: clustered %lld (%zu tiles), natural %lld (%zu tiles)\n",
+              c_ok ? (long long)C.nhalo : -1LL, C.tiles.size(), n_ok ? (long long)N.nhalo : -1LL,
+              N.tiles.size());
     if (!c_ok) use_clustered = false;
     else if (n_ok && (sizeof(V) == 8 ? 2 * N.nhalo <= 5 * C.nhalo : N.nhalo <= 6 * C.nhalo))
       use_clustered = false;
@@ -1213,10 +1492,10 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   if (use_clustered &&
       build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in, opt,
                          &chunk, &perm, P)) {
-    sp.valid = true; // a later build with half as many groups may reuse it
+    sp.valid = true; // a later build with half as many chunks may reuse it
     sp.rb = rb;
     sp.re = re;
-    sp.ngroups = ngroups;
+    sp.nchunks = nchunks;
     return true;
   }
   std::vector<int32_t>().swap(bci);
@@ -1256,16 +1535,22 @@ bool set_recv(SymPlan<V> &P, int nrecv, const int *recv_rows) {
 }
 
 // Decode the device format back into (row, col, value) triples of the strict
-// lower triangle (original numbering), walking it exactly as the kernel does (packets, jagged
-// diagonals, slot -> column through the own range / halo map).  Structure
-// check for the CPU test-suite; performs no SpMV arithmetic.
+// lower triangle (original numbering), walking it exactly as the kernel does (packets,
+// jagged diagonals, slot -> column through the own range / halo map, far sections).
+// Structure check for the CPU test-suite; performs no SpMV arithmetic.  `up_*`
+// (optional) receive the mirrored far entries as (higher row, lower row, value): as
+// a multiset they must equal the far entries of the lower side, `far_*`.
 template <typename V>
 void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
-                 std::vector<int32_t> &col, std::vector<V> &val) {
+                 std::vector<int32_t> &col, std::vector<V> &val,
+                 std::vector<int32_t> *far_row = nullptr, std::vector<int32_t> *far_col = nullptr,
+                 std::vector<V> *far_val = nullptr, std::vector<int32_t> *up_row = nullptr,
+                 std::vector<int32_t> *up_col = nullptr, std::vector<V> *up_val = nullptr) {
   row.clear();
   col.clear();
   val.clear();
   const int rb = P.row_begin;
+  auto orig = [&](int c) { return (!P.perm.empty() && c >= rb && c < P.row_end) ? P.perm[c - rb] : c; };
   for (const Tile &t : P.tiles) {
     const V *tv = P.vals.data() + t.nnz_off;
     const uint16_t *ts = P.slots.data() + t.sl_off;
@@ -1296,8 +1581,8 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
         int nlead = 0;
         for (int l = 0; l < cnt; l++) {
           if ((sm.leaders >> l) & 1) nlead++;
-          const int L = ll[l];
-          const int rank = __builtin_popcountll(sm.leaders & ((1ull << L) - 1));
+          const int Ld = ll[l];
+          const int rank = __builtin_popcountll(sm.leaders & ((1ull << Ld) - 1));
           for (int j = 0; j < kPacket; j++)
             rows_out[r[l]].push_back({slot_col(ts[os + packet_slot_pos(rank, j)]),
                                       tv[o + packet_val_pos<V>(l, j, cnt)]});
@@ -1315,7 +1600,6 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
           {slot_col(cc[pk * 256 + packet_slot_pos(l, j)]),
            cv[pk * 256 + packet_val_pos<V>(l, j)]});
     }
-    auto orig = [&](int c) { return (!P.perm.empty() && c >= rb && c < P.row_end) ? P.perm[c - rb] : c; };
     for (int rr = 0; rr < t.nown; rr++)
       for (auto &e : rows_out[rr]) {
         const int a = orig(t.row0 + rr), b = orig(e.first);
@@ -1323,6 +1607,31 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
         col.push_back(std::min(a, b));
         val.push_back(e.second);
       }
+    // far section: columns are stored in ORIGINAL numbering already
+    const V *fv = P.fvals.data() + t.far_off;
+    const uint16_t *fr = P.frows.data() + t.far_off;
+    const int32_t *fc = P.fcols.data() + t.far_off;
+    for (int64_t e = 0; e < t.nfar; e++) {
+      const int64_t pk = e >> 8;
+      const int l = (int)((e & 255) >> 2), j = (int)(e & 3);
+      const int a = orig(t.row0 + fr[pk * 256 + packet_slot_pos(l, j)]);
+      const int b = fc[pk * 256 + packet_slot_pos(l, j)];
+      const V v = fv[pk * 256 + packet_val_pos<V>(l, j)];
+      if (e < t.nfar_low) {
+        row.push_back(std::max(a, b));
+        col.push_back(std::min(a, b));
+        val.push_back(v);
+        if (far_row) {
+          far_row->push_back(std::max(a, b));
+          far_col->push_back(std::min(a, b));
+          far_val->push_back(v);
+        }
+      } else if (up_row) {
+        up_row->push_back(std::max(a, b));
+        up_col->push_back(std::min(a, b));
+        up_val->push_back(v);
+      }
+    }
   }
 }
 

@@ -45,18 +45,34 @@ static inline double offdiag(uint64_t seed, int i, int j) {
 }
 
 typedef struct {
-  int kind;           /* 0 = grid stencil, 1 = banded-random */
+  int kind;           /* 0 = grid stencil, 1 = banded-random, 2 = point cloud (unstructured) */
   int n;              /* rows */
   int nx, ny, nz, dof;/* grid */
   int pts;            /* 27 or 7 */
   int irregular;      /* ldoor-like: 2% fat rows, 5% thin rows */
   int per_row, mean_off, cap_off; /* banded-random */
   uint64_t seed;
+  /* point cloud: lower node neighbours (ascending) of every node, in the final numbering */
+  int knn, bfs;
+  long *adj_ptr;
+  int *adj;
 } spec_t;
 
 /* strictly-lower column list of row i (ascending, unique).  Returns count. */
 static int lower_cols(const spec_t *sp, int i, int *out, int cap) {
   int cnt = 0;
+  if (sp->kind == 2) {
+    /* unstructured: dof x dof blocks with the lower node neighbours, then the own node */
+    const int dof = sp->dof, node = i / dof;
+    for (long k = sp->adj_ptr[node]; k < sp->adj_ptr[node + 1]; k++)
+      for (int e = 0; e < dof; e++) {
+        const int c = sp->adj[k] * dof + e;
+        if (c < sp->n && cnt < cap) out[cnt++] = c;
+      }
+    for (int e = 0; e < i % dof; e++)
+      if (cnt < cap) out[cnt++] = node * dof + e;
+    return cnt; /* ascending and unique by construction */
+  }
   if (sp->kind == 1) {
     /* pdb1HYS-like: per_row draws at offsets 1 + floor(Exp(mean)) capped */
     for (int k = 0; k < sp->per_row && cnt < cap; k++) {
@@ -150,6 +166,18 @@ static int make_spec(const char *name, double scale, spec_t *sp) {
     sp->n = (int)(4147110 * scale);
     sp->dof = 3; sp->pts = 27;
     sp->nx = (int)ceil(112 * s3); sp->ny = (int)ceil(112 * s3); sp->nz = (int)ceil(111 * s3);
+  } else if (!strcmp(name, "unstruct") || !strcmp(name, "unstruct_bfs")) {
+    /* a non-regular stand-in of Flan_1565's size: random points in the unit cube, each
+     * node tied to its 21 nearest neighbours (symmetrised: ~24 neighbours, ~75 nonzeros
+     * per row with 3 dof, as the real hex-mesh matrix), 3 dof per node.  "unstruct"
+     * keeps the random node numbering (no locality at all in the natural order);
+     * "unstruct_bfs" renumbers breadth-first from a corner (an RCM-like band). */
+    sp->kind = 2;
+    sp->n = (int)(1564794 * scale);
+    sp->dof = 3;
+    sp->knn = 21;
+    sp->bfs = !strcmp(name, "unstruct_bfs");
+    sp->seed = fnv1a("unstruct"); /* both orders are the SAME graph */
   } else {
     return -1;
   }
@@ -159,6 +187,163 @@ static int make_spec(const char *name, double scale, spec_t *sp) {
     long need = ((long)sp->n + sp->dof - 1) / sp->dof;
     while ((long)sp->nx * sp->ny * sp->nz < need) sp->nz++;
   }
+  return 0;
+}
+
+
+/* ---- point cloud -> k-nearest-neighbour graph (kind 2) ------------------------------ */
+static int cmp_u64(const void *a, const void *b) {
+  const uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b;
+  return x < y ? -1 : x > y;
+}
+static int build_cloud(spec_t *sp) {
+  const int N = (sp->n + sp->dof - 1) / sp->dof, K = sp->knn;
+  float *px = (float *)malloc(sizeof(float) * 3 * (size_t)N);
+  if (!px) return -1;
+  for (int v = 0; v < N; v++)
+    for (int d = 0; d < 3; d++)
+      px[3 * (size_t)v + d] = (float)u01(splitmix64(sp->seed ^ ((uint64_t)v * 3 + (uint64_t)d + 0x5bd1e995ULL)));
+  /* buckets of ~6 points */
+  int G = (int)ceil(cbrt((double)N / 6.0));
+  if (G < 1) G = 1;
+  const long ncell = (long)G * G * G;
+  int *cstart = (int *)calloc((size_t)ncell + 1, sizeof(int));
+  int *cell = (int *)malloc(sizeof(int) * (size_t)N), *order = (int *)malloc(sizeof(int) * (size_t)N);
+  for (int v = 0; v < N; v++) {
+    int cx = (int)(px[3 * (size_t)v] * G), cy = (int)(px[3 * (size_t)v + 1] * G), cz = (int)(px[3 * (size_t)v + 2] * G);
+    if (cx >= G) cx = G - 1;
+    if (cy >= G) cy = G - 1;
+    if (cz >= G) cz = G - 1;
+    cell[v] = cx + G * (cy + G * cz);
+    cstart[cell[v] + 1]++;
+  }
+  for (long c = 0; c < ncell; c++) cstart[c + 1] += cstart[c];
+  {
+    int *fill = (int *)malloc(sizeof(int) * (size_t)ncell);
+    memcpy(fill, cstart, sizeof(int) * (size_t)ncell);
+    for (int v = 0; v < N; v++) order[fill[cell[v]]++] = v;
+    free(fill);
+  }
+  /* K nearest of every node among the points of the 27 (or, where too few, 125) cells around it */
+  uint64_t *edges = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)N * (size_t)K);
+  long nedge_cap = (long)N * K;
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int v = 0; v < N; v++) {
+    int best[64];
+    float bd[64];
+    int nb = 0;
+    const int cx = cell[v] % G, cy = (cell[v] / G) % G, cz = cell[v] / (G * G);
+    for (int R = 1; R <= 3; R++) {
+      nb = 0;
+      for (int dz = -R; dz <= R; dz++)
+        for (int dy = -R; dy <= R; dy++)
+          for (int dx = -R; dx <= R; dx++) {
+            const int X = cx + dx, Y = cy + dy, Z = cz + dz;
+            if (X < 0 || Y < 0 || Z < 0 || X >= G || Y >= G || Z >= G) continue;
+            const long c = X + (long)G * (Y + (long)G * Z);
+            for (int q = cstart[c]; q < cstart[c + 1]; q++) {
+              const int u = order[q];
+              if (u == v) continue;
+              const float ax = px[3 * (size_t)u] - px[3 * (size_t)v], ay = px[3 * (size_t)u + 1] - px[3 * (size_t)v + 1],
+                          az = px[3 * (size_t)u + 2] - px[3 * (size_t)v + 2];
+              const float dd = ax * ax + ay * ay + az * az;
+              if (nb < K || dd < bd[nb - 1]) { /* insertion into the sorted K best */
+                int p = nb < K ? nb++ : K - 1;
+                while (p > 0 && (bd[p - 1] > dd || (bd[p - 1] == dd && best[p - 1] > u))) {
+                  bd[p] = bd[p - 1];
+                  best[p] = best[p - 1];
+                  p--;
+                }
+                bd[p] = dd;
+                best[p] = u;
+              }
+            }
+          }
+      if (nb >= K || R * 2 + 1 >= G) break;
+    }
+    for (int k = 0; k < K; k++) {
+      uint64_t key = ~0ULL; /* unused slots sort to the end */
+      if (k < nb) {
+        const uint64_t a = (uint64_t)(v < best[k] ? v : best[k]), b = (uint64_t)(v < best[k] ? best[k] : v);
+        key = (b << 32) | a; /* (higher, lower) */
+      }
+      edges[(size_t)v * K + k] = key;
+    }
+  }
+  qsort(edges, (size_t)nedge_cap, sizeof(uint64_t), cmp_u64);
+  long ne = 0;
+  for (long k = 0; k < nedge_cap; k++)
+    if (edges[k] != ~0ULL && (ne == 0 || edges[k] != edges[ne - 1])) edges[ne++] = edges[k];
+  /* numbering: as generated (random), or breadth-first from the node nearest the origin */
+  int *label = (int *)malloc(sizeof(int) * (size_t)N);
+  for (int v = 0; v < N; v++) label[v] = v;
+  if (sp->bfs) {
+    long *ap = (long *)calloc((size_t)N + 1, sizeof(long));
+    for (long k = 0; k < ne; k++) {
+      ap[(edges[k] >> 32) + 1]++;
+      ap[(edges[k] & 0xffffffffULL) + 1]++;
+    }
+    for (int v = 0; v < N; v++) ap[v + 1] += ap[v];
+    int *aj = (int *)malloc(sizeof(int) * (size_t)(2 * ne + 1));
+    long *fill = (long *)malloc(sizeof(long) * (size_t)N);
+    memcpy(fill, ap, sizeof(long) * (size_t)N);
+    for (long k = 0; k < ne; k++) {
+      const int hi = (int)(edges[k] >> 32), lo = (int)(edges[k] & 0xffffffffULL);
+      aj[fill[hi]++] = lo;
+      aj[fill[lo]++] = hi;
+    }
+    free(fill);
+    int start = 0;
+    float bestd = 1e30f;
+    for (int v = 0; v < N; v++) {
+      const float dd = px[3 * (size_t)v] + px[3 * (size_t)v + 1] + px[3 * (size_t)v + 2];
+      if (dd < bestd) {
+        bestd = dd;
+        start = v;
+      }
+    }
+    int *queue = (int *)malloc(sizeof(int) * (size_t)N);
+    for (int v = 0; v < N; v++) label[v] = -1;
+    int head = 0, tail = 0, next_seed = 0;
+    queue[tail++] = start;
+    label[start] = 0;
+    int cnt = 1;
+    while (head < N) {
+      if (head == tail) { /* disconnected remainder */
+        while (label[next_seed] >= 0) next_seed++;
+        label[next_seed] = cnt++;
+        queue[tail++] = next_seed;
+      }
+      const int v = queue[head++];
+      for (long q = ap[v]; q < ap[v + 1]; q++) /* neighbours in stored (ascending-id) order */
+        if (label[aj[q]] < 0) {
+          label[aj[q]] = cnt++;
+          queue[tail++] = aj[q];
+        }
+    }
+    free(queue);
+    free(ap);
+    free(aj);
+  }
+  /* lower node lists in the final numbering */
+  for (long k = 0; k < ne; k++) {
+    const uint64_t a = (uint64_t)label[edges[k] >> 32], b = (uint64_t)label[edges[k] & 0xffffffffULL];
+    edges[k] = ((a > b ? a : b) << 32) | (a > b ? b : a);
+  }
+  qsort(edges, (size_t)ne, sizeof(uint64_t), cmp_u64);
+  sp->adj_ptr = (long *)calloc((size_t)N + 1, sizeof(long));
+  sp->adj = (int *)malloc(sizeof(int) * (size_t)(ne + 1));
+  for (long k = 0; k < ne; k++) {
+    sp->adj_ptr[(edges[k] >> 32) + 1]++;
+    sp->adj[k] = (int)(edges[k] & 0xffffffffULL); /* sorted by (higher, lower): in place */
+  }
+  for (int v = 0; v < N; v++) sp->adj_ptr[v + 1] += sp->adj_ptr[v];
+  free(edges);
+  free(label);
+  free(px);
+  free(cstart);
+  free(cell);
+  free(order);
   return 0;
 }
 
@@ -174,6 +359,7 @@ int cfs_synth_generate(const char *name, double scale, int *n_out,
   if (make_spec(name, scale, &sp) != 0) return -1;
   const int n = sp.n;
   const int CAP = 2048;
+  if (sp.kind == 2 && build_cloud(&sp) != 0) return -3;
   /* pass 1: lower counts */
   long *lptr = (long *)calloc((size_t)n + 1, sizeof(long));
 #pragma omp parallel
@@ -247,6 +433,8 @@ int cfs_synth_generate(const char *name, double scale, int *n_out,
   free(lcol);
   free(ucnt);
   free(upos);
+  free(sp.adj_ptr);
+  free(sp.adj);
   *n_out = n;
   *nnz_full_out = nnz_full;
   *nnz_low_out = nnz_low;

@@ -115,7 +115,8 @@ class SymMatrix:
     (csr_matrix.tpp:74-107).  `row_splits`/`rank` build one 1-D row block of a
     sharded matrix."""
 
-    def __init__(self, n, rowptr, colind, values, options=None, row_splits=None, rank=0):
+    def __init__(self, n, rowptr, colind, values, options=None, row_splits=None, rank=0,
+                 ngpus=1, devices=None):
         lib = _lib.load()
         rowptr, colind = _np_i32(rowptr), _np_i32(colind)
         values = np.ascontiguousarray(values)
@@ -126,7 +127,15 @@ class SymMatrix:
         suf = "f64" if self.dtype == np.float64 else "f32"
         self._h = C.c_void_p()
         optp = C.byref(options) if options is not None else None
-        if row_splits is None:
+        if ngpus > 1:
+            # one host thread, ngpus shards (cfs_hip_sym_create_multi_*: what the C++
+            # surface builds for CFS_NUM_GPUS); shards may share devices
+            dv = _np_i32(devices) if devices is not None else None
+            _lib.check(getattr(lib, "cfs_hip_sym_create_multi_" + suf)(
+                n, rowptr.ctypes.data, colind.ctypes.data, values.ctypes.data, int(ngpus),
+                dv.ctypes.data if dv is not None else None, optp, C.byref(self._h)))
+            self.nranks, self.rank = 1, 0
+        elif row_splits is None:
             _lib.check(getattr(lib, "cfs_hip_sym_create_" + suf)(
                 n, rowptr.ctypes.data, colind.ctypes.data, values.ctypes.data, optp,
                 C.byref(self._h)))

@@ -9,6 +9,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 NAMES = ("pdb1HYS", "pwtk", "ldoor", "Flan_1565", "Queen_4147")
+# non-regular stand-ins (SURVEY 7 "structure-faithful synthetic generators"): a random 3-D
+# point cloud, 21 nearest neighbours, 3 dof per node; random / breadth-first numbering
+UNSTRUCTURED = ("unstruct", "unstruct_bfs")
 
 
 def _lib():

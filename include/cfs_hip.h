@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CFS_HIP_ABI_VERSION 2
+#define CFS_HIP_ABI_VERSION 3
 
 /* error codes */
 #define CFS_HIP_OK 0
@@ -101,13 +101,12 @@ typedef struct {
 #define CFS_HIP_FLAG_NO_REORDER 8
 /* always keep the clustered order (skip the halo-count comparison)            */
 #define CFS_HIP_FLAG_FORCE_CLUSTER 16
-/* tune() of a matrix with >= 2M stored nonzeros measures: (1) when no block /
- * slot count is given and the rows are scheduled in clustered order, the default
- * window shape (512 threads x 2 workgroups per CU) against 1024 threads x 1 with a
- * window twice the size, keeping the faster; (2) from 16M stored nonzeros, the
- * per-XCD finish times of a few launches, re-cutting the rows with per-XCD work
- * shares (kept only if the launches end earlier).  This flag skips both (one
- * schedule build).                                                            */
+/* tune() of a matrix with >= 2M stored nonzeros measures alternatives and keeps the
+ * fastest: when no block / slot count is given and the rows are scheduled in
+ * clustered order, the default window shape (512 threads x 2 workgroups per CU)
+ * against 1024 threads x 1 with a window twice the size; when a noticeable share of
+ * the halo columns is used only once, the HYB form against the plain one.  This
+ * flag skips the measurements (one schedule build; Tuning::None).              */
 #define CFS_HIP_FLAG_NO_CALIBRATE 32
 /* Shards only.  Default: off-block entries are MIRRORED -- stored by both ranks
  * they touch and processed one-sided, so that no contribution to y ever leaves
@@ -116,6 +115,25 @@ typedef struct {
  * shard keeps its off-block entries two-sided and packs its contributions to
  * rows of lower ranks for an all-to-all / reduce-scatter (the exchange form). */
 #define CFS_HIP_FLAG_SHARD_EXCHANGE 64
+/* Format::hyb (the reference's split_by_bandwidth, csr_matrix.tpp:312-401, as a
+ * working feature): an entry whose column lies outside its tile and is used by that
+ * tile only once leaves the symmetric tile format.  It is stored by BOTH tiles it
+ * touches as (value, own row slot, global column) and processed one-sided with x
+ * gathered from global memory -- no LDS slot, no strip entry, no fold entry.  With
+ * the flag the split is always made; without it tune() may still choose it by
+ * measurement (see CFS_HIP_FLAG_NO_CALIBRATE); CFS_HIP_FLAG_NO_HYB forbids it.     */
+#define CFS_HIP_FLAG_HYB 128
+#define CFS_HIP_FLAG_NO_HYB 256
+/* Bit-reproducible results.  By default the transposed updates y_j += a_ij x_i of a
+ * tile meet in LDS through floating-point atomics, whose order varies from run to
+ * run: results agree to ~1e-13 of the row scale, not bitwise (the reference adds in a
+ * fixed order, csr_matrix.tpp:3005-3013).  With this flag every contribution is
+ * converted to a fixed-point number (2 x 40 bits below a per-tile scale derived from
+ * max|a| and max|x|) and accumulated with INTEGER LDS atomics -- associative, hence
+ * the same bits whatever the order; the halo fold already adds in a fixed order.
+ * Costs LDS (24 instead of 16 bytes per slot: smaller tiles) and ALU; no far entries,
+ * 512-thread workgroups only.  Same tolerance against the oracle as the default.   */
+#define CFS_HIP_FLAG_DETERMINISTIC 1024
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->
@@ -147,6 +165,20 @@ int cfs_hip_sym_create_shard_f32(int n, const int *rowptr, const int *colind,
                                  const float *values, int nranks, int rank,
                                  const int *row_splits,
                                  const cfs_hip_options *opt, cfs_hip_sym_t *out);
+/* One host thread, `ngpus` GPUs (the C++ surface with CFS_NUM_GPUS; the reference's
+ * knob of this kind is CFS_NUM_THREADS, src/runtime.cpp:10-21): ngpus mirrored row
+ * blocks, shard g on devices[g] (NULL: the visible devices round-robin from the
+ * current one; several shards may share a device), each on a stream of its own.
+ * The handle behaves like a whole-matrix one: cfs_hip_sym_spmv[_async] take x / y
+ * of n entries on the device that was current at create (or host pointers);
+ * shards on other devices reach them through peer access.                      */
+int cfs_hip_sym_create_multi_f64(int n, const int *rowptr, const int *colind,
+                                 const double *values, int ngpus, const int *devices,
+                                 const cfs_hip_options *opt, cfs_hip_sym_t *out);
+int cfs_hip_sym_create_multi_f32(int n, const int *rowptr, const int *colind,
+                                 const float *values, int ngpus, const int *devices,
+                                 const cfs_hip_options *opt, cfs_hip_sym_t *out);
+int cfs_hip_sym_num_gpus(cfs_hip_sym_t h, int *ngpus); /* shards of the handle (1: plain) */
 /* nnz_low-balanced row boundaries (multiples of 16, csr_matrix.tpp:418) for
  * sharding; row_splits has nranks+1 entries.                                 */
 int cfs_hip_sym_balanced_splits(int n, const int *rowptr, const int *colind,
@@ -224,6 +256,9 @@ typedef struct {
   int64_t device_bytes; /* device memory held by the handle               */
   int64_t mirror_entries; /* one-sided entries a mirrored shard stores for rows of
                              higher ranks (0 for a whole matrix / exchange form)  */
+  int64_t far_entries; /* HYB: nonzeros kept outside the tile format (each stored twice) */
+  int ngroups;         /* persistent workgroups of a launch                          */
+  int reserved_;
 } cfs_hip_sym_stats;
 int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out);
 /* developer diagnostic: one extra launch of the tile kernel that records, per
@@ -258,6 +293,7 @@ typedef struct {
   int64_t decoded;    /* triples recovered from the device format           */
   int64_t mismatches; /* 0 = the schedule encodes exactly the input         */
   int64_t mirror_entries; /* mirrored off-block entries (shards, default form)  */
+  int64_t far_entries;    /* HYB: nonzeros outside the tile format (mirror images checked) */
 } cfs_hip_plan_report;
 int cfs_hip_sym_plan_check_f64(int n, const int *rowptr, const int *colind,
                                const double *values, int nranks, int rank,

@@ -24,6 +24,11 @@ int get_host_threads();
 int get_device();
 // number of HIP devices visible; 0 means the GPU path cannot run
 int get_num_devices();
+// CFS_NUM_GPUS: GPUs one matrix is sharded over by tune() (1-D row blocks, one HIP
+// stream per device, driven by the calling thread).  Parsed like CFS_NUM_THREADS
+// (src/runtime.cpp:10-21 of the reference): unset -> 1, below 1 -> 1.  More shards
+// than visible devices share devices round-robin.
+int get_num_gpus();
 // wait for every SpMV enqueued on Platform::gpu vectors (a benchmark loop calls
 // this once before it stops its clock)
 void synchronize();

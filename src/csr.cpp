@@ -116,7 +116,18 @@ bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning t) {
     cfs_hip_options opt;
     memset(&opt, 0, sizeof opt);
     if (t == Tuning::None) opt.flags |= CFS_HIP_FLAG_NO_CALIBRATE;
-    if (std::is_same<ValueT, double>::value)
+    // Format::hyb (csr_matrix.tpp:312-401 in the reference): entries whose column a
+    // tile uses only once leave the tile format (kept by both tiles, one-sided)
+    if (hybrid_) opt.flags |= CFS_HIP_FLAG_HYB;
+    const int ngpus = cfs::util::runtime::get_num_gpus();
+    if (ngpus > 1) { // CFS_NUM_GPUS: one shard per GPU, one stream each, this thread drives them
+      if (std::is_same<ValueT, double>::value)
+        rc = cfs_hip_sym_create_multi_f64(nrows_, rowptr_, colind_, (const double *)values_, ngpus,
+                                          nullptr, &opt, &h);
+      else
+        rc = cfs_hip_sym_create_multi_f32(nrows_, rowptr_, colind_, (const float *)values_, ngpus,
+                                          nullptr, &opt, &h);
+    } else if (std::is_same<ValueT, double>::value)
       rc = cfs_hip_sym_create_f64(nrows_, rowptr_, colind_, (const double *)values_, &opt, &h);
     else
       rc = cfs_hip_sym_create_f32(nrows_, rowptr_, colind_, (const float *)values_, &opt, &h);
@@ -139,7 +150,8 @@ bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning t) {
     device_bytes_ = (size_t)st.device_bytes;
 #ifdef _LOG_INFO
     std::cout << "[INFO]: " << st.ntiles << " tiles, " << st.halo_slots << " halo slots, "
-              << st.lds_bytes << " B LDS per workgroup" << std::endl;
+              << st.far_entries << " far entries, " << st.lds_bytes << " B LDS per workgroup, "
+              << cfs::util::runtime::get_num_gpus() << " shard(s)" << std::endl;
 #endif
     release_host_csr(); // csr_matrix.tpp:1700-1706
   } else {

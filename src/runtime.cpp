@@ -55,6 +55,17 @@ int get_device() {
   return d < 0 ? 0 : d;
 }
 
+int get_num_gpus() {
+  const char *env = getenv("CFS_NUM_GPUS");
+  int ret = 1;
+  if (env) {
+    ret = atoi(env);
+    if (ret < 1) ret = 1;
+    if (ret > 64) ret = 64;
+  }
+  return ret;
+}
+
 int get_num_devices() {
   int n = 0;
   if (cfs_hip_device_count(&n) != 0) return 0;

@@ -22,7 +22,7 @@ def header_symbols():
 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = cfs.load()
-    assert lib.cfs_hip_abi_version() == 2
+    assert lib.cfs_hip_abi_version() == 3
     syms = header_symbols()
     assert len(syms) >= 30
     for name in syms:
@@ -68,6 +68,48 @@ def test_schedule_encodes_the_lower_triangle(name, scale, dtype):
     assert rep["decoded"] == rep["nnz_low"] == low
     assert rep["ngroups"] % 8 == 0 and rep["ntiles"] >= 1
     assert rep["stream_len"] <= low + 8 * rep["nslices"] + 8 * rep["ntiles"]  # no padding entries
+
+
+FLAG_HYB, FLAG_CLUSTER, FLAG_NO_REORDER, FLAG_EXCHANGE = 128, 16, 8, 64
+
+
+@pytest.mark.parametrize("name,scale", CASES + [("Flan_1565", 0.2), ("ldoor", 0.3)])
+@pytest.mark.parametrize("flags", [FLAG_HYB, FLAG_HYB | FLAG_CLUSTER, FLAG_HYB | FLAG_NO_REORDER])
+def test_hyb_schedules_encode_the_lower_triangle(name, scale, flags):
+    """Format::hyb (far entries kept by both tiles they touch, one-sided): the decoded
+    triples are still exactly the strict lower triangle and every far entry has exactly
+    one mirror image (checked inside cfs_hip_sym_plan_check_*)"""
+    n, rp, ci, va, low = synth.generate(name, scale)
+    rep = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(flags=flags))
+    assert rep["mismatches"] == 0 and rep["decoded"] == rep["nnz_low"] == low
+    base = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(flags=flags & ~FLAG_HYB))
+    assert base["far_entries"] == 0
+    # (the rows are re-cut with the far entries priced in: a few slots either way)
+    assert rep["far_entries"] >= 0 and rep["halo_slots"] <= 1.02 * base["halo_slots"] + 64
+
+
+def test_hyb_takes_the_single_use_halo_columns_out():
+    """ldoor stand-in: 2 % fat rows scatter single entries over a 40 000-row window;
+    each of them costs a halo slot (slot table, x gather, strip, fold) for one nonzero"""
+    n, rp, ci, va, low = synth.generate("ldoor", 0.3)
+    plain = cfs.plan_check(n, rp, ci, va)
+    hyb = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(flags=FLAG_HYB))
+    assert hyb["mismatches"] == 0
+    assert hyb["far_entries"] > 0.02 * low
+    assert hyb["halo_slots"] < 0.7 * plain["halo_slots"]
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+@pytest.mark.parametrize("flags", [FLAG_HYB, FLAG_HYB | FLAG_EXCHANGE])
+def test_hyb_shards(nranks, flags):
+    n, rp, ci, va, low = synth.generate("ldoor", 0.1)
+    rs = cfs.balanced_splits(n, rp, ci, nranks)
+    tot = 0
+    for r in range(nranks):
+        rep = cfs.plan_check(n, rp, ci, va, nranks, r, rs, options=cfs.make_options(flags=flags))
+        assert rep["mismatches"] == 0
+        tot += rep["nnz_low"]
+    assert tot == low
 
 
 @pytest.mark.parametrize("slots,block", [(64, 256), (128, 512), (777, 256), (2560, 512),
