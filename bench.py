@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--cpu-loops", type=int, default=128,
                     help="timed SpMVs of each cpu_baseline leg (the reference driver's protocol: "
                          "loops/2 warm-up, loops timed; SURVEY 8d asks for 128)")
+    ap.add_argument("--cpu-bind", action="store_true",
+                    help="OMP_PLACES=cores OMP_PROC_BIND=close for the cpu_baseline legs")
     ap.add_argument("--no-exchange-forms", action="store_true",
                     help="N>1: skip the extra timings of the other two exchange forms")
     ap.add_argument("--exchange", default="none", choices=["none", "all_to_all", "reduce_scatter"],
@@ -63,6 +65,16 @@ def parse():
                          "ranks it touches and no SpMV needs a collective (default); "
                          "'all_to_all' = packed contributions to lower ranks, one sparse "
                          "all-to-all; 'reduce_scatter' = the dense form over padded blocks")
+    ap.add_argument("--tuning", default="aggressive", choices=["aggressive", "none"],
+                    help="Tuning::Aggressive (the reference's default: tune() also measures "
+                         "alternatives and keeps the fastest) or Tuning::None (one schedule build)")
+    ap.add_argument("--flags", type=int, default=0, help="extra CFS_HIP_FLAG_* bits (hyb = 128, "
+                                                         "deterministic = 1024, ...)")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="N=1 only: time ONE rank's mirrored row block of an N-way split on this "
+                         "GPU (what every rank of the driver's N-GPU run executes per step; no "
+                         "process group).  value / roofline then refer to that block")
+    ap.add_argument("--shard-rank", type=int, default=0)
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the tile kernel with HIP events on every n-th timed step")
     return ap.parse_args()
@@ -85,17 +97,17 @@ def host_cpus():
     return max(1, cores)
 
 
-def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
+def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops, threads, bound):
     """the oracle's restatement of the reference's two CPU paths on the host cores,
     same matrix, same x, reference protocol (loops/2 warm-up, loops timed,
     bench/bench_spmv_mmf.cpp:154-167): cpu_mv_sym_conflict_free_v2
     (csr_matrix.tpp:2965-3028; `value`) and plain CSR cpu_mv (:2683-2704; `csr`).
-    OMP_PLACES=cores OMP_PROC_BIND=close are set by main() before any OpenMP runtime
-    is loaded."""
+    `threads` = the CPUs this process may use, counted BEFORE any OpenMP runtime was
+    loaded (a bound runtime shrinks the main thread's mask)."""
     import ctypes as C
     import numpy as np
     from oracle import oracle
-    T = max(1, min(host_cpus(), 96))  # MaxThreads = 96, include/utils/runtime.hpp:15
+    T = max(1, min(threads, 96))  # MaxThreads = 96, include/utils/runtime.hpp:15
     t0 = time.time()
     o = oracle.SymOracle(n, rp, ci, va, T)
     preproc = time.time() - t0
@@ -126,7 +138,9 @@ def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops):
     return {
         "value": round(2.0 * nnz_full / dt / 1e9, 2), "unit": "GFLOP/s", "cores": T,
         "kind": "port",
-        "sample": f"whole workload, OMP_PLACES=cores OMP_PROC_BIND=close: {loops // 2} warm-up + "
+        "sample": f"whole workload, threads "
+                  f"{'bound (OMP_PLACES=cores OMP_PROC_BIND=close)' if bound else 'unbound'}: "
+                  f"{loops // 2} warm-up + "
                   f"{loops} timed SpMVs of the oracle's conflict-free v2 path "
                   f"({info['ncolors']} colours), {dt * 1e3:.2f} ms/SpMV; same protocol for the "
                   f"plain-CSR cpu_mv leg, {dt_csr * 1e3:.2f} ms/SpMV.  The oracle's preprocessing "
@@ -225,14 +239,21 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and os.environ.get("CFS_FORCE_DIST") != "1":
         raise SystemExit(self_launch(args))
-    # the CPU baseline's binding; must precede the first OpenMP runtime
-    os.environ.setdefault("OMP_PLACES", "cores")
-    os.environ.setdefault("OMP_PROC_BIND", "close")
+    # the CPU baseline's binding (OMP_PLACES=cores OMP_PROC_BIND=close) is an
+    # OPT-IN here (--cpu-bind): measured on the MI355X boxes (a 256-CPU host shared by
+    # containers with a 16-CPU quota each) it binds every tenant's threads to the same
+    # first cores -- the oracle's v2 path fell from 103 to 16 GFLOP/s and tune() from 1.2
+    # to 3.0 s -- and it shrinks the main thread's affinity mask to one core.  It must
+    # precede the first OpenMP runtime.
+    if args.cpu_bind:
+        os.environ.setdefault("OMP_PLACES", "cores")
+        os.environ.setdefault("OMP_PROC_BIND", "close")
     # host-side setup (matrix generator, schedule build) is OpenMP code: give every
     # rank of this node an equal share of the CPUs (torchrun presets
     # OMP_NUM_THREADS=1 for N > 1, which would serialise it).  Set before any
     # OpenMP runtime is loaded.
-    share = max(1, host_cpus() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
+    ncpus = host_cpus()
+    share = max(1, ncpus // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))
     os.environ["OMP_NUM_THREADS"] = str(share)
     os.environ["CFS_HOST_THREADS"] = str(share)
     import numpy as np
@@ -296,10 +317,16 @@ def main():
     va = va.astype(np_dt, copy=False)
     nnz_full = int(rp[-1])
     x_host = synth.make_x(n, 42, np_dt)
-    opt = cfs.make_options(max_slots=args.max_slots, block_threads=args.block)
+    opt = cfs.make_options(max_slots=args.max_slots, block_threads=args.block,
+                           flags=args.flags | (32 if args.tuning == "none" else 0))
 
     t0 = time.time()
-    if N == 1 and not force_dist:
+    rs = None
+    if N == 1 and not force_dist and args.shard_of > 1:
+        rs = cfs.balanced_splits(n, rp, ci, args.shard_of)
+        A = cfs.SymMatrix(n, rp, ci, va, options=opt, row_splits=rs, rank=args.shard_rank)
+        sh = None
+    elif N == 1 and not force_dist:
         A = cfs.SymMatrix(n, rp, ci, va, options=opt)
         sh = None
     else:
@@ -390,6 +417,29 @@ def main():
     for e in list(ev0.values()) + list(ev1.values()):
         lib.cfs_hip_event_destroy(e)
 
+    # cross-check with the kernel's own clock (developer timeline build of the same
+    # launch: first workgroup start -> last workgroup end, 100 MHz wall clock).  A HIP
+    # event bracket also holds the dispatch latency around the kernel (~2-3 us: 2 % of
+    # a 110 us launch, 20 % of a 13 us one); rocprofv3's kernel duration is the
+    # counterpart of this number.
+    tl_ms = None
+    try:
+        tbuf = np.zeros(8 * 8192, dtype=np.uint64)
+        ng = C.c_int()
+        spans = []
+        for _ in range(5):
+            _lib.check(lib.cfs_hip_sym_debug_timeline(A._h, y.data_ptr(), x.data_ptr(),
+                                                      tbuf.ctypes.data, tbuf.size, C.byref(ng)))
+            tt = tbuf[:ng.value * 8].reshape(-1, 8).astype(np.int64)
+            spans.append((tt[:, 3].max() - tt[:, 0].min()) / 100.0 * 1e-3)
+        tl_ms = float(np.median(spans))
+        phases(3 if local_only else 1 | 4)  # y of a complete step again for the self-check
+        if not local_only:
+            sh.finish(y, x)
+        torch.cuda.synchronize()
+    except Exception:
+        tl_ms = None
+
     alg_bytes = st["bytes_algorithmic"]  # this rank's rows: nnz_low*(4+s) + rows*(4+3s)
     achieved = alg_bytes / (tile_ms * 1e-3) / 1e9
     # HBM bytes per launch from the PMC passes (profiles/hbm_traffic.json, written by
@@ -402,7 +452,10 @@ def main():
         try:
             with open(tpath) as f:
                 tj = json.load(f)
-            ent = tj.get(f"{args.matrix}:{args.scale}:{args.dtype}:{N}", {})
+            key = f"{args.matrix}:{args.scale}:{args.dtype}:{N}"
+            if args.shard_of > 1:
+                key += f":shard{args.shard_rank}of{args.shard_of}"
+            ent = tj.get(key, {})
             same = all(ent.get(k) == st[k] for k in ("bytes_streamed", "lds_bytes", "block_threads"))
             traffic = ent.get("hbm_bytes_per_launch") if same else None
         except Exception:
@@ -421,37 +474,49 @@ def main():
     if not err < (1e-9 if args.dtype == "f64" else 1e-3):
         raise SystemExit(f"rank {rank}: self-check failed: max scaled |y - y_csr| = {err}")
 
+    # what one step multiplies: the whole matrix, or (--shard-of) the rows of one block
+    shard_mode = args.shard_of > 1 and sh is None
+    nnz_step = int(rp[st["row_end"]] - rp[st["row_begin"]]) if shard_mode else nnz_full
+    alg_step = int(st["bytes_algorithmic"]) if shard_mode else \
+        int(nnz_low * (4 + va.itemsize) + n * (4 + 3 * va.itemsize))
     out = None
     if rank == 0:
         out = {
             "metric": "fp64 symmetric SpMV GFLOP/s" if args.dtype == "f64"
                       else "fp32 symmetric SpMV GFLOP/s",
-            "value": round(2.0 * nnz_full / (ms_per_step * 1e-3) / 1e9, 2),
+            "value": round(2.0 * nnz_step / (ms_per_step * 1e-3) / 1e9, 2),
             "unit": "GFLOP/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None,
             "dtype": args.dtype, "data": data_kind,
             "config": {
                 "workload": f"{source}: n={n}, nnz_full={nnz_full}, "
-                            f"nnz_low={nnz_low}, symmetric SSS SpMV y=Ax",
-                "format": "sss", "sharding": f"1d-row-blocks x{N}",
+                            f"nnz_low={nnz_low}, symmetric SSS SpMV y=Ax" +
+                            (f"; ONLY the mirrored row block of rank {args.shard_rank} of "
+                             f"{args.shard_of} (rows {st['row_begin']}..{st['row_end']}, "
+                             f"{nnz_step} of the nonzeros): one rank's step of an "
+                             f"{args.shard_of}-GPU run, timed alone" if shard_mode else ""),
+                "format": "hyb" if st.get("far_entries", 0) else "sss",
+                "far_entries": st.get("far_entries", 0), "halo_slots": st["halo_slots"],
+                "sharding": f"1d-row-blocks x{N}",
                 "exchange": (None if sh is None else
                              "none: off-block entries mirrored on both ranks, no collective "
                              "per SpMV" if args.exchange == "none" else args.exchange),
                 "mirror_entries_rank0": st.get("mirror_entries", 0),
-                "algorithmic_bytes_per_spmv": int(nnz_low * (4 + va.itemsize)
-                                                  + n * (4 + 3 * va.itemsize)),
-                "effective_GBps_whole_step": round(
-                    (nnz_low * (4 + va.itemsize) + n * (4 + 3 * va.itemsize))
-                    / (ms_per_step * 1e-3) / 1e9, 1),
+                "algorithmic_bytes_per_spmv": alg_step,
+                "effective_GBps_whole_step": round(alg_step / (ms_per_step * 1e-3) / 1e9, 1),
                 "tiles": st["ntiles"], "lds_bytes": st["lds_bytes"],
                 "block_threads": st["block_threads"], "preproc_s": round(preproc, 2),
+                "tuning": args.tuning, "flags": args.flags,
             },
             "roofline": {
                 "bound": "hbm", "kernel": "cfs_sym_tile_kernel",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel_ms": round(tile_ms, 5), "kernel_samples": len(sampled),
+                "kernel_ms_inkernel_clock": round(tl_ms, 5) if tl_ms else None,
+                "frac_inkernel_clock": (round(alg_bytes / (tl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                                        if tl_ms else None),
                 "algorithmic_bytes_per_launch": int(alg_bytes),
                 # `achieved` is ALGORITHMIC bytes / kernel time (the device format streams
                 # fewer: 16-bit de-duplicated slots); what really crossed the HBM interface:
@@ -461,9 +526,10 @@ def main():
             },
         }
 
-    if rank == 0 and N == 1 and not args.no_cpu_baseline:
+    if rank == 0 and N == 1 and not args.no_cpu_baseline and not shard_mode:
         try:
-            out["cpu_baseline"] = cpu_baseline(n, rp, ci, va, x_host, nnz_full, args.cpu_loops)
+            out["cpu_baseline"] = cpu_baseline(n, rp, ci, va, x_host, nnz_full, args.cpu_loops,
+                                               ncpus, args.cpu_bind)
         except Exception as e:  # the baseline is reported, never required
             out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0,
                                    "kind": "port", "sample": f"failed: {e}"}

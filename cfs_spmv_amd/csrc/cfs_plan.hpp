@@ -340,6 +340,7 @@ template <typename V> struct Builder {
   struct VRow {
     int32_t r, k0, a; // local row, first packet of the chunk, packets in the chunk
   };
+  std::vector<std::vector<VRow>> vrows; // [T] the virtual rows of every tile, slice order
 
   Builder(int n_, const int *rp, const int *ci, const V *va, int nranks_, int rank_,
           const Options &o, const std::vector<int32_t> *chunks, const std::vector<int32_t> *perm,
@@ -739,12 +740,13 @@ template <typename V> struct Builder {
     const int T = (int)P.tiles.size();
     tile_len.assign(T, 0);
     tile_slen.assign(T, 0);
+    vrows.assign(T, std::vector<VRow>());
 #pragma omp parallel num_threads(host_threads())
     {
-      std::vector<VRow> vr;
 #pragma omp for schedule(dynamic, 1)
       for (int ti = 0; ti < T; ti++) {
         Tile &t = P.tiles[ti];
+        std::vector<VRow> &vr = vrows[ti];
         build_vrows(t, vr);
         t.nvrows = (int32_t)vr.size();
         t.nslices = (t.nvrows + kLanes - 1) / kLanes;
@@ -789,13 +791,12 @@ template <typename V> struct Builder {
     P.nvrows = nvr;
 #pragma omp parallel num_threads(host_threads())
     {
-      std::vector<VRow> vr;
       std::vector<int32_t> cur;
       std::vector<std::vector<int32_t>> lseq(kLanes); // sequences of the slice's leaders
 #pragma omp for schedule(dynamic, 1)
       for (int ti = 0; ti < T; ti++) {
         Tile &t = P.tiles[ti];
-        build_vrows(t, vr);
+        const std::vector<VRow> &vr = vrows[ti];
         int64_t off = 0, soff = 0;
         for (int s = 0; s < t.nslices; s++) {
           off = align_up(off, kAlignEntries);
@@ -903,7 +904,6 @@ template <typename V> struct Builder {
     {
       std::vector<int32_t> colmap(n > 0 ? n : 1, -1); // col -> halo slot (per thread)
       std::vector<int32_t> hcols, lowj;
-      std::vector<VRow> vr;
       std::vector<FarE> fl;
 #pragma omp for schedule(dynamic, 1)
       for (int ti = 0; ti < T; ti++) {
@@ -949,7 +949,7 @@ template <typename V> struct Builder {
           for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
             if (near(i, j)) out.push_back(j);
         };
-        build_vrows(t, vr);
+        const std::vector<VRow> &vr = vrows[ti];
         V *tv = P.vals.data() + t.nnz_off;
         uint16_t *ts = P.slots.data() + t.sl_off;
         std::vector<std::vector<int32_t>> low(kLanes);
@@ -1211,32 +1211,34 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 // The cost of a cluster is exact: a row's stored (lower) entries in the new
 // order are its neighbours left of the block plus its neighbours assigned
 // before it, and the sum over a cluster does not depend on the order inside.
+// one sweep over the rows [pb, pe) of the block [.., block_re): columns left of pb are
+// outside (their entries are stored at the row whatever the order), columns in
+// [pe, block_re) belong to a later sweep (numbered later: not stored at this row)
 template <typename V>
-void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, int ngroups,
-                  const std::vector<double> &share, std::vector<int32_t> &perm,
-                  std::vector<int32_t> &chunk, bool mirror = false) {
-  const int rows = re - rb;
+void cluster_rows_part(const int *rowptr, const int *colind, int pb, int pe, int block_re,
+                       int ngroups, const double *share, std::vector<int32_t> &perm,
+                       std::vector<int32_t> &chunk, bool mirror) {
+  const int rows = pe - pb;
   const int64_t per_nz = (int64_t)sizeof(V) + 2, per_row = 4 + 5 * (int64_t)sizeof(V);
   int64_t total = (int64_t)rows * per_row, inblock = 0;
-  for (int i = rb; i < re; i++)
+  for (int i = pb; i < pe; i++)
     for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
       int c = colind[j];
-      if (c < rb || (mirror && c >= re)) total += per_nz;
-      else if (c < re && c != i) inblock++;
+      if (c < pb || (mirror && c >= block_re)) total += per_nz;
+      else if (c < pe && c != i) inblock++;
     }
   total += inblock / 2 * per_nz;
   perm.clear();
   perm.reserve(rows);
-  chunk.assign(ngroups + 1, re);
-  chunk[0] = rb;
+  chunk.assign(ngroups + 1, pe);
+  chunk[0] = pb;
   std::vector<int32_t> state(rows, -1); // -1 free, -2-g queued for cluster g, >=0 assigned
   std::vector<int32_t> bfs, seeds;
   size_t seed_head = 0;
   int next_free = 0;
   int64_t cum = 0;
   std::vector<double> cumshare(ngroups + 1, 0.0);
-  for (int g = 0; g < ngroups; g++)
-    cumshare[g + 1] = cumshare[g] + ((int)share.size() == ngroups ? std::max(share[g], 1e-9) : 1.0);
+  for (int g = 0; g < ngroups; g++) cumshare[g + 1] = cumshare[g] + std::max(share[g], 1e-9);
   for (int g = 0; g < ngroups; g++) {
     const int64_t target = (g == ngroups - 1)
                                ? total + 1
@@ -1264,12 +1266,12 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
       }
       const int v = bfs[head++];
       int low = 0;
-      const int i = rb + v;
+      const int i = pb + v;
       for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
         const int c = colind[j];
-        if (c < rb || (mirror && c >= re)) low++;
-        else if (c < re && c != i) {
-          const int u = c - rb;
+        if (c < pb || (mirror && c >= block_re)) low++;
+        else if (c < pe && c != i) {
+          const int u = c - pb;
           if (state[u] >= 0) low++;
           else if (state[u] != -2 - g) {
             state[u] = -2 - g;
@@ -1286,8 +1288,89 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
       seeds.push_back(bfs[k]);
     }
     std::sort(perm.begin() + first, perm.end()); // original order inside a cluster
-    chunk[g + 1] = rb + (int)perm.size();
+    chunk[g + 1] = pb + (int)perm.size();
   }
+}
+
+// The sweep is sequential by nature; a large block is cut into up to 8 PARTS of
+// consecutive rows (equal shares of the cost, whole clusters each) that are swept
+// independently, one host thread each.  Across a part boundary the natural order
+// decides which end stores an entry, as it does across the tiles of the natural
+// order; inside a part nothing changes.  (A small block keeps the single sweep: that
+// is what numbers the hub rows of an arrow matrix early.)
+template <typename V>
+void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, int ngroups,
+                  const std::vector<double> &share_in, std::vector<int32_t> &perm,
+                  std::vector<int32_t> &chunk, bool mirror = false) {
+  (void)n;
+  const int rows = re - rb;
+  std::vector<double> share(ngroups, 1.0);
+  if ((int)share_in.size() == ngroups) share = share_in;
+  int parts = 1;
+  if (rows >= 200000 && ngroups >= 64)
+    while (parts * 2 <= std::min(host_threads(), 8) && ngroups % (parts * 2) == 0 &&
+           ngroups / (parts * 2) >= 16)
+      parts *= 2;
+  if (parts == 1) {
+    cluster_rows_part<V>(rowptr, colind, rb, re, re, ngroups, share.data(), perm, chunk, mirror);
+    return;
+  }
+  // part boundaries: the cost every order agrees on (an entry across a boundary is
+  // stored at its higher row either way), split by the shares of the parts' clusters
+  const int64_t per_nz = (int64_t)sizeof(V) + 2, per_row = 4 + 5 * (int64_t)sizeof(V);
+  std::vector<int64_t> cost((size_t)rows + 1, 0);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+  for (int i = rb; i < re; i++) {
+    int low = 0;
+    for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
+      if (colind[j] < i || (mirror && colind[j] >= re)) low++;
+    cost[i - rb + 1] = (int64_t)low * per_nz + per_row;
+  }
+  for (int r = 0; r < rows; r++) cost[r + 1] += cost[r];
+  const int gpp = ngroups / parts;
+  std::vector<double> cum(parts + 1, 0.0);
+  for (int p = 0; p < parts; p++) {
+    cum[p + 1] = cum[p];
+    for (int g = 0; g < gpp; g++) cum[p + 1] += std::max(share[p * gpp + g], 1e-9);
+  }
+  std::vector<int> pb(parts + 1, re);
+  pb[0] = rb;
+  for (int p = 1; p < parts; p++) {
+    const int64_t target = (int64_t)((double)cost[rows] * (cum[p] / cum[parts]));
+    int r = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
+    pb[p] = std::max(pb[p - 1], rb + std::min(r, rows));
+  }
+  { // parts only pay when the given order has locality: most neighbours of a row must
+    // lie in its own part (a randomly numbered mesh has them everywhere -- one sweep then)
+    int64_t inpart = 0, inblock = 0;
+#pragma omp parallel for schedule(static) reduction(+ : inpart, inblock) num_threads(host_threads())
+    for (int i = rb; i < re; i++) {
+      const int p = (int)(std::upper_bound(pb.begin(), pb.end(), i) - pb.begin()) - 1;
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        const int c = colind[j];
+        if (c < rb || c >= re || c == i) continue;
+        inblock++;
+        if (c >= pb[p] && c < pb[p + 1]) inpart++;
+      }
+    }
+    if (inpart * 10 < inblock * 8) {
+      cluster_rows_part<V>(rowptr, colind, rb, re, re, ngroups, share.data(), perm, chunk, mirror);
+      return;
+    }
+  }
+  std::vector<std::vector<int32_t>> pperm(parts), pchunk(parts);
+#pragma omp parallel for schedule(static, 1) num_threads(parts)
+  for (int p = 0; p < parts; p++)
+    cluster_rows_part<V>(rowptr, colind, pb[p], pb[p + 1], re, gpp, share.data() + p * gpp,
+                         pperm[p], pchunk[p], mirror);
+  perm.clear();
+  perm.reserve(rows);
+  chunk.assign(ngroups + 1, re);
+  for (int p = 0; p < parts; p++) {
+    perm.insert(perm.end(), pperm[p].begin(), pperm[p].end());
+    for (int g = 0; g <= gpp; g++) chunk[p * gpp + g] = pchunk[p][g]; // row counts == positions
+  }
+  chunk[ngroups] = re;
 }
 
 // The clustered row order of a block and its matrix in schedule space: what a

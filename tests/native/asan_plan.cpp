@@ -1,7 +1,8 @@
 // Host-only sanitizer harness for the tile schedule builder (cfs_plan.hpp is pure
 // host C++): builds and decodes schedules of small synthetic matrices -- node
-// blocks, bands, hub rows; natural / clustered order; whole matrix, mirrored and
-// exchange-form shards -- under AddressSanitizer + UBSan.  Compiled and run by
+// blocks, bands, hub rows; natural / clustered order; HYB (far entries) and the
+// deterministic layout; whole matrix, mirrored and exchange-form shards -- under
+// AddressSanitizer + UBSan.  Compiled and run by
 // tests/test_native_sanitizers.py (CPU only; GPU sanitizers are not available).
 #include <cstdio>
 #include <cstdlib>
@@ -71,6 +72,8 @@ template <typename V> static long run(const Csr &A, int nranks, bool mirror, int
     o.block_threads = block;
     o.reorder = !(flags & 8);
     if (flags & 16) o.force_order = 2;
+    o.hyb = (flags & 128) != 0;          // far entries (Format::hyb)
+    o.deterministic = (flags & 1024) != 0; // two integer words per y slot: smaller windows
     o.mirror_offblock = mirror;
     cfs_plan::SymPlan<V> P;
     if (!cfs_plan::build_plan<V>(A.n, A.rp.data(), A.ci.data(), va.data(), nranks, r,
@@ -81,9 +84,14 @@ template <typename V> static long run(const Csr &A, int nranks, bool mirror, int
       }
       continue;
     }
-    std::vector<int32_t> rr, cc;
-    std::vector<V> vv;
-    cfs_plan::decode_plan(P, rr, cc, vv);
+    std::vector<int32_t> rr, cc, fr, fc, ur, uc;
+    std::vector<V> vv, fv, uv;
+    cfs_plan::decode_plan(P, rr, cc, vv, &fr, &fc, &fv, &ur, &uc, &uv);
+    if ((int64_t)fr.size() != P.far_entries || fr.size() != ur.size()) {
+      fprintf(stderr, "far entries %zu, mirror images %zu, expected %lld\n", fr.size(), ur.size(),
+              (long long)P.far_entries);
+      exit(5);
+    }
     if ((int64_t)rr.size() != P.nnz_low + P.mirror_entries) {
       fprintf(stderr, "decoded %zu entries, expected %lld\n", rr.size(),
               (long long)(P.nnz_low + P.mirror_entries));
@@ -100,7 +108,7 @@ int main() {
   for (int kind = 0; kind < 3; kind++)
     for (int dof : {1, 3, 7}) {
       const Csr A = make(700 / dof + 40, dof, kind, 17u * kind + dof);
-      for (int flags : {0, 8, 16})
+      for (int flags : {0, 8, 16, 128, 128 | 8, 128 | 16, 1024})
         for (int nranks : {1, 3}) {
           total += run<double>(A, nranks, true, flags, kind == 2 ? 0 : 192, 256);
           total += run<float>(A, nranks, nranks > 1 ? false : true, flags, 0, 512);

@@ -1,0 +1,46 @@
+"""bench.py --gpus N without a torchrun environment: the parent must start the N ranks
+itself as a CHILD process (it never touches HIP) and pass the child's exit code on.
+On this CPU box the ranks exit with "needs a GPU" -- which is exactly what shows that
+they were started, that they got a torchrun environment, and that a failing child makes
+the parent fail."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_self_launches_ranks_and_propagates_failure():
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = ""  # no GPU for the children whatever the box has
+    env["HIP_VISIBLE_DEVICES"] = ""
+    env["ROCR_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+                        "--warmup", "1", "--matrix", "pwtk", "--scale", "0.01"],
+                       capture_output=True, text=True, env=env, timeout=600)
+    err = r.stderr
+    assert "launching 2 ranks" in err and "torch.distributed.run" in err, err[-2000:]
+    assert "--nproc-per-node=2" in err and "--master-addr 127.0.0.1" in err
+    # both ranks ran bench.py under torchrun and refused to run without a GPU
+    assert err.count("bench.py needs a GPU") >= 1, err[-3000:]
+    assert r.returncode != 0  # a child failure is the parent's failure
+    assert r.stdout.strip() == ""  # and no JSON line was invented
+
+
+def test_bench_does_not_relaunch_inside_torchrun(monkeypatch):
+    """with WORLD_SIZE set (the driver's own torchrun launch) bench.py must NOT spawn"""
+    sys.path.insert(0, ROOT)
+    import importlib
+    bench = importlib.import_module("bench")
+    called = []
+    monkeypatch.setattr(bench, "self_launch", lambda a: called.append(a) or 0)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2"])
+    try:
+        bench.main()
+    except SystemExit:
+        pass
+    except Exception:
+        pass  # no GPU / no process group here: irrelevant
+    assert not called

@@ -1,40 +1,57 @@
 #!/bin/bash
 # Round profile: run on the GPU box (gpurun).  Produces, under gpurun_out/<tag>/:
-#   bench.json                 the contract line of `python bench.py`
+#   bench.json                 the contract line of `python bench.py <args>`
 #   kernel_stats.csv           rocprofv3 --kernel-trace --stats of the same command
 #   pmc_fetch.csv, pmc_write.csv   separate --pmc passes (never combined with tracing)
-#   hbm_traffic.json           per-launch HBM bytes of cfs_sym_tile_kernel:
+#   hbm_traffic.json           per-launch HBM bytes of the kernels:
 #                              (2*FETCH_SIZE + WRITE_SIZE) KiB, the gfx950 correction of
 #                              /opt/skills/guides/MI355X_MICROARCH.md (FETCH_SIZE counts 128-B
-#                              requests at 64 B for wide coalesced reads; WRITE_SIZE is exact)
+#                              requests at 64 B for wide coalesced reads; WRITE_SIZE is exact),
+#                              with the schedule it was measured on (bytes_streamed, lds_bytes,
+#                              block_threads): bench.py quotes roofline.traffic only for the same
 # usage: tools/profile_round.sh <tag> [bench args...]
 export TMPDIR=/tmp
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
 python3 bench.py "$@" > $out/bench.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
-cat $out/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" > $out/bench_traced.json 2> $out/trace.err
 cp $out/trace/*/*_kernel_stats.csv $out/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/pmc_f.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pmc_w -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/pmc_w.err
 cp $out/pmc_f/*/*_counter_collection.csv $out/pmc_fetch.csv
 cp $out/pmc_w/*/*_counter_collection.csv $out/pmc_write.csv
-python3 - $out "$@" <<'PY'
+rm -rf $out/trace $out/pmc_f $out/pmc_w
+python3 - $out <<'PY'
 import csv, json, sys
 out = sys.argv[1]
+b = json.load(open(out + '/bench.json'))
 def mean(path, counter, kern):
     v = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
          if r['Counter_Name'] == counter and kern in r['Kernel_Name']]
-    return sum(v) / len(v), len(v)
-res = {}
+    return (sum(v) / len(v), len(v)) if v else (0.0, 0)
+res = {"bench_config": b["config"]["workload"][:120], "lds_bytes": b["config"]["lds_bytes"],
+       "block_threads": b["config"]["block_threads"],
+       "bytes_streamed": b["roofline"]["bytes_streamed_by_format"]}
 for kern in ("cfs_sym_tile_kernel", "cfs_fold_kernel"):
     f, nf = mean(out + '/pmc_fetch.csv', 'FETCH_SIZE', kern)
     w, nw = mean(out + '/pmc_write.csv', 'WRITE_SIZE', kern)
     res[kern] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "launches": [nf, nw],
                  "hbm_bytes_per_launch": int((2 * f + w) * 1024),
                  "correction": "reads = 2 x FETCH_SIZE (gfx950: 128-B requests tallied at 64 B), writes exact"}
-json.dump(res, open(out + '/hbm_traffic_raw.json', 'w'), indent=1)
-print(json.dumps(res))
+json.dump(res, open(out + '/hbm_traffic.json', 'w'), indent=1)
+# keep the per-dispatch csv small: the tile / fold kernels only
+for name in ('pmc_fetch.csv', 'pmc_write.csv'):
+    rows = list(csv.DictReader(open(out + '/' + name)))
+    keep = [r for r in rows if 'cfs_' in r['Kernel_Name']]
+    with open(out + '/' + name, 'w', newline='') as fo:
+        w = csv.DictWriter(fo, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep[:400])
+ks = [r for r in csv.DictReader(open(out + '/kernel_stats.csv'))]
+t = [r for r in ks if 'cfs_sym_tile_kernel' in r['Name']]
+avg = sum(float(r['TotalDurationNs']) for r in t) / max(1, sum(int(r['Calls']) for r in t))
+print(json.dumps({"tag": out, "ms_per_step": b["ms_per_step"], "value": b["value"],
+                  "kernel_ms_events": b["roofline"]["kernel_ms"], "kernel_ms_rocprof": round(avg * 1e-6, 5),
+                  "frac": b["roofline"]["frac"], "hbm_bytes_tile": res["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"],
+                  "alg_bytes": b["roofline"]["algorithmic_bytes_per_launch"], "preproc_s": b["config"]["preproc_s"],
+                  "cpu": b.get("cpu_baseline", {}).get("value")}))
 PY
-head -4 $out/kernel_stats.csv | cut -c1-200
