@@ -1,21 +1,40 @@
-"""The committed bench line (profiles/r01_bench.json, written by `python bench.py` on an
-MI355X) carries every field of the driver's contract, and its numbers are consistent
-with one another and with the committed rocprofv3 / PMC summaries."""
+"""The committed bench lines (profiles/r02_<cfg>_bench.json, written by `python bench.py` on an
+MI355X through tools/profile_round.sh) carry every field of the driver's contract, and their
+numbers are consistent with one another and with the committed rocprofv3 / PMC summaries."""
 import csv
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, "profiles")
+# cfg -> (key in hbm_traffic.json, dtype, has a cpu_baseline)
+SETS = {
+    "flan": ("Flan_1565:1.0:f64:1", "f64", True),
+    "pwtk": ("pwtk:1.0:f64:1", "f64", True),
+    "ldoor": ("ldoor:1.0:f64:1", "f64", True),
+    "pdb1HYS": ("pdb1HYS:1.0:f64:1", "f64", True),
+    "unstruct": ("unstruct:1.0:f64:1", "f64", True),
+    "queen_f32": ("Queen_4147:1.0:f32:1", "f32", True),
+    "flan_shard8": ("Flan_1565:1.0:f64:1:shard3of8", "f64", False),
+    "queen_f32_shard8": ("Queen_4147:1.0:f32:1:shard3of8", "f32", False),
+}
 
 
-def test_committed_bench_line_matches_the_contract():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench.json")).read())
+def _bench(cfg):
+    return json.loads(open(os.path.join(PROF, f"r02_{cfg}_bench.json")).read())
+
+
+@pytest.mark.parametrize("cfg", sorted(SETS))
+def test_committed_bench_line_matches_the_contract(cfg):
+    key, dtype, has_cpu = SETS[cfg]
+    d = _bench(cfg)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
-              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-              "roofline", "cpu_baseline"):
+              "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in d, k
     assert d["unit"] == "GFLOP/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
-    assert d["n_gpus"] == 1 and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert d["n_gpus"] == 1 and d["dtype"] == dtype and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -23,29 +42,65 @@ def test_committed_bench_line_matches_the_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     # achieved = algorithmic bytes per launch / measured kernel time
-    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) < 1.0
-    # the value is 2 * nnz_full / t (bench/bench_spmv_mmf.cpp:168)
-    nnz_full = int(d["config"]["workload"].split("nnz_full=")[1].split(",")[0])
-    assert abs(d["value"] - 2.0 * nnz_full / (d["ms_per_step"] * 1e-3) / 1e9) < 0.5
-    c = d["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+    assert abs(r["achieved"] - r["algorithmic_bytes_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) \
+        <= 1e-3 * r["achieved"]  # (kernel_ms is printed with five decimals)
+    assert r["kernel_ms"] <= d["ms_per_step"]
+    # the value is 2 * nnz / t (bench/bench_spmv_mmf.cpp:168), nnz of what one step multiplies
+    w = d["config"]["workload"]
+    nnz = int(w.split(" of the nonzeros")[0].split(", ")[-1]) if "ONLY the mirrored row block" in w \
+        else int(w.split("nnz_full=")[1].split(",")[0])
+    assert abs(d["value"] - 2.0 * nnz / (d["ms_per_step"] * 1e-3) / 1e9) < 0.5
+    if has_cpu:
+        c = d["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample", "csr"):
+            assert k in c, k
+        assert c["kind"] in ("port", "reference") and c["cores"] >= 1
+        assert "128 timed" in c["sample"] and c["csr"]["value"] > 0
+    else:
+        assert "cpu_baseline" not in d
 
 
-def test_rocprof_summary_agrees_with_the_bench_line():
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_bench.json")).read())
-    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r01_kernel_stats.csv"))))
+@pytest.mark.parametrize("cfg", sorted(SETS))
+def test_rocprof_summary_agrees_with_the_bench_line(cfg):
+    d = _bench(cfg)
+    rows = list(csv.DictReader(open(os.path.join(PROF, f"r02_{cfg}_kernel_stats.csv"))))
     tile = [r for r in rows if "cfs_sym_tile_kernel" in r["Name"]]
     assert tile, "tile kernel missing from the rocprofv3 summary"
     calls = sum(int(r["Calls"]) for r in tile)
-    avg_ns = sum(float(r["TotalDurationNs"]) for r in tile) / calls
-    # HIP events in bench.py vs rocprofv3's kernel trace of the same command: within 5 %
-    assert abs(avg_ns * 1e-6 - d["roofline"]["kernel_ms"]) <= 0.05 * d["roofline"]["kernel_ms"]
-    # PMC traffic (separate passes) is what the line reports, and it is below the
-    # algorithmic figure: no re-reads
-    t = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")))
-    assert d["roofline"]["traffic"] is not None
-    assert abs(t["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"] - d["roofline"]["traffic"]) \
-        <= 0.01 * d["roofline"]["traffic"]
-    assert d["roofline"]["traffic"] < d["roofline"]["algorithmic_bytes_per_launch"]
+    avg_ms = sum(float(r["TotalDurationNs"]) for r in tile) / calls * 1e-6
+    ev = d["roofline"]["kernel_ms"]
+    # HIP events in bench.py vs rocprofv3's kernel trace of the same command.  The event bracket
+    # also holds the dispatch latency (~2.5-3 us): within 3 % for launches of 100 us and more,
+    # never below rocprofv3's duration, at most 3.5 us above it for the short ones
+    assert avg_ms <= ev * 1.03
+    assert ev - avg_ms <= max(0.03 * avg_ms, 0.0035)
+    clk = d["roofline"]["kernel_ms_inkernel_clock"]
+    assert clk is not None and clk <= avg_ms * 1.02  # first workgroup start -> last workgroup end
+    # PMC traffic (separate passes): what hbm_traffic.json quotes for this workload
+    t = json.load(open(os.path.join(PROF, f"r02_{cfg}_hbm_traffic.json")))
+    table = json.load(open(os.path.join(PROF, "hbm_traffic.json")))
+    ent = table[SETS[cfg][0]]
+    assert ent["hbm_bytes_per_launch"] == t["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"]
+    # ... measured on the schedule of the committed line
+    assert ent["bytes_streamed"] == d["roofline"]["bytes_streamed_by_format"]
+    assert ent["lds_bytes"] == d["config"]["lds_bytes"]
+    assert ent["block_threads"] == d["config"]["block_threads"]
+    # no wasted re-reads: the memory interface sees at most a few per cent more than the
+    # algorithmic bytes (less where the 16-bit de-duplicated slots pay), cache-resident
+    # matrices included (Infinity-Cache hits appear to be counted)
+    assert ent["hbm_bytes_per_launch"] <= 1.15 * d["roofline"]["algorithmic_bytes_per_launch"]
+
+
+def test_headline_meets_the_target():
+    """BASELINE: >= 70 % of the HBM3E peak on the Flan_1565 configuration at one GPU"""
+    d = _bench("flan")
+    assert d["roofline"]["frac"] >= 0.70
+    assert d["config"]["effective_GBps_whole_step"] >= 0.70 * 8000.0
+
+
+def test_multi_rank_rehearsals_report_all_exchange_forms():
+    for name in ("r02_n2_rehearsal_gloo_bench.json", "r02_n1_rccl_forced_dist_bench.json"):
+        d = json.loads(open(os.path.join(PROF, name)).read())
+        f = d["exchange_forms"]
+        assert set(f) == {"none", "all_to_all", "reduce_scatter"}
+        assert all(isinstance(v, float) and v > 0 for v in f.values()), f

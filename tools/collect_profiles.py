@@ -1,0 +1,27 @@
+"""copy the per-config evidence of tools/profile_round.sh from gpurun_out/<round>/<cfg>/ into
+profiles/<round>_<cfg>_* (tracked) and rebuild profiles/hbm_traffic.json, the table bench.py
+reads for roofline.traffic (keyed by workload, validated against the schedule that runs).
+usage: collect_profiles.py r02 flan=Flan_1565:1.0:f64:1 pwtk=pwtk:1.0:f64:1 ..."""
+import json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1]
+table_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+table = {}
+for arg in sys.argv[2:]:
+    cfg, key = arg.split("=")
+    src = os.path.join(ROOT, "gpurun_out", rnd, cfg)
+    for name in ("bench.json", "kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "hbm_traffic.json"):
+        shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_{name}"))
+    t = json.load(open(os.path.join(src, "hbm_traffic.json")))
+    table[key] = {
+        "hbm_bytes_per_launch": t["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"],
+        "kernel": "cfs_sym_tile_kernel",
+        # the schedule the counters were taken on: bench.py quotes the number only for the same
+        "bytes_streamed": t["bytes_streamed"], "lds_bytes": t["lds_bytes"],
+        "block_threads": t["block_threads"],
+        "source": f"profiles/{rnd}_{cfg}_pmc_fetch.csv + _pmc_write.csv (rocprofv3 --pmc FETCH_SIZE / "
+                  "WRITE_SIZE, separate passes); reads = 2 x FETCH_SIZE KiB (gfx950 correction), "
+                  "writes = WRITE_SIZE KiB",
+    }
+json.dump(table, open(table_path, "w"), indent=1)
+print(json.dumps(table, indent=1))
