@@ -1434,7 +1434,10 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     }
     return 0;
   };
-  if (tuning && !m->P.perm.empty() && po.block_threads == 0 && po.max_slots == 0) {
+  // (natural-order schedules are tried too: a 1/8 row block of the Flan stand-in runs 11 %
+  // faster with 256 workgroups of 1 024 threads -- a third less halo, half as many window
+  // phases per CU -- while pwtk, ldoor and Queen stay with the default)
+  if (tuning && po.block_threads == 0 && po.max_slots == 0) {
     cfs_plan::Options po2 = po;
     po2.block_threads = 1024;
     po2.max_slots = 2 * cfs_plan::kDefaultSlots;

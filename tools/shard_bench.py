@@ -9,6 +9,7 @@ from cfs_spmv_amd import synth
 name, scale, N = sys.argv[1], float(sys.argv[2]), int(sys.argv[3])
 ranks = [int(a) for a in sys.argv[4:]] or list(range(N))
 flags = int(os.environ.get("SB_FLAGS", "0"))
+slots, block = int(os.environ.get("SB_SLOTS", "0")), int(os.environ.get("SB_BLOCK", "0"))
 n, rp, ci, va, low = synth.generate(name, scale)
 if os.environ.get("QB_DTYPE") == "f32":
     va = va.astype(np.float32)
@@ -16,7 +17,7 @@ x = torch.from_numpy(synth.make_x(n, 42, va.dtype)).cuda()
 rs = cfs.balanced_splits(n, rp, ci, N)
 for r in ranks:
     t0 = time.time()
-    A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=flags), row_splits=rs, rank=r)
+    A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(slots, 0, block, flags), row_splits=rs, rank=r)
     pre = time.time() - t0
     st = A.stats()
     y = torch.empty(st["row_end"] - st["row_begin"], dtype=x.dtype, device="cuda")
