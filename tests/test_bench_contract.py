@@ -70,10 +70,10 @@ def test_rocprof_summary_agrees_with_the_bench_line(cfg):
     avg_ms = sum(float(r["TotalDurationNs"]) for r in tile) / calls * 1e-6
     ev = d["roofline"]["kernel_ms"]
     # HIP events in bench.py vs rocprofv3's kernel trace of the same command.  The event bracket
-    # also holds the dispatch latency (~2.5-3 us): within 3 % for launches of 100 us and more,
-    # never below rocprofv3's duration, at most 3.5 us above it for the short ones
+    # also holds the dispatch latency (~2.5-4 us): within 3 % for launches of 100 us and more,
+    # never below rocprofv3's duration, at most 4.5 us above it for the short ones
     assert avg_ms <= ev * 1.03
-    assert ev - avg_ms <= max(0.03 * avg_ms, 0.0035)
+    assert ev - avg_ms <= max(0.03 * avg_ms, 0.0045)
     clk = d["roofline"]["kernel_ms_inkernel_clock"]
     assert clk is not None and clk <= avg_ms * 1.02  # first workgroup start -> last workgroup end
     # PMC traffic (separate passes): what hbm_traffic.json quotes for this workload
