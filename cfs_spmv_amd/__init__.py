@@ -11,5 +11,5 @@ directory is `cfs_spmv_amd`.)
   synth.py, csrc/cfs_synth.c           synthetic SuiteSparse stand-ins (workload only)
 """
 from ._lib import CfsHipError, load, lib_path  # noqa: F401
-from .matrix import (FLAG_SHARD_EXCHANGE, CsrMatrix, Format, Kernel, SpDMV, SymMatrix, Tuning,  # noqa: F401
+from .matrix import (FLAG_KEEP_VALUE_MAP, FLAG_SHARD_EXCHANGE, CsrMatrix, Format, Kernel, SpDMV, SymMatrix, Tuning,  # noqa: F401
                      balanced_splits, make_options, plan_check, plan_send_info)

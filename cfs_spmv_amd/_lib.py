@@ -51,7 +51,7 @@ SYMBOLS = [
     "cfs_hip_current_device", "cfs_hip_pinned_owns", "cfs_hip_pinned_pool_stats", "cfs_hip_default_stream", "cfs_hip_synchronize", "cfs_hip_alloc", "cfs_hip_free",
     "cfs_hip_memcpy", "cfs_hip_memset", "cfs_hip_sym_create_f64", "cfs_hip_sym_create_f32",
     "cfs_hip_sym_create_shard_f64", "cfs_hip_sym_create_shard_f32",
-    "cfs_hip_sym_create_multi_f64", "cfs_hip_sym_create_multi_f32", "cfs_hip_sym_num_gpus", "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_spmv",
+    "cfs_hip_sym_create_multi_f64", "cfs_hip_sym_create_multi_f32", "cfs_hip_sym_num_gpus", "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_update_values_f64", "cfs_hip_sym_update_values_f32", "cfs_hip_sym_spmv",
     "cfs_hip_sym_spmv_async", "cfs_hip_sym_shard_send_counts", "cfs_hip_sym_shard_send_rows",
     "cfs_hip_sym_shard_set_recv", "cfs_hip_sym_spmv_local_async",
     "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_debug_group_features", "cfs_hip_sym_plan_check_f64",
@@ -108,6 +108,8 @@ def load():
     lib.cfs_hip_sym_balanced_splits.argtypes = [C.c_int, vp, vp, C.c_int, vp]
     lib.cfs_hip_sym_num_gpus.argtypes = [vp, ip]
     lib.cfs_hip_sym_destroy.argtypes = [vp]
+    lib.cfs_hip_sym_update_values_f64.argtypes = [vp, vp, C.c_longlong]
+    lib.cfs_hip_sym_update_values_f32.argtypes = [vp, vp, C.c_longlong]
     lib.cfs_hip_sym_spmv.argtypes = [vp, vp, vp]
     lib.cfs_hip_sym_spmv_async.argtypes = [vp, vp, vp, vp]
     lib.cfs_hip_sym_shard_send_counts.argtypes = [vp, vp]

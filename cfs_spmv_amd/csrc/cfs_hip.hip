@@ -646,6 +646,20 @@ __global__ void __launch_bounds__(256)
   if (i < m) y[r] = s;
 }
 
+// new values into an existing schedule (cfs_hip_sym_update_values_*): every entry of a
+// value array of the device format takes the caller's value at its recorded position
+// (GPU-side packing of the values: the sparsity pattern, and with it the whole schedule
+// -- tiles, slots, leaders, fold index -- stays)
+template <typename V>
+__global__ void __launch_bounds__(256)
+    cfs_value_scatter_kernel(V *__restrict__ dst, const int32_t *__restrict__ map,
+                             const V *__restrict__ src, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int32_t m = map[i];
+    dst[i] = m >= 0 ? src[m] : V(0);
+  }
+}
+
 // pack contributions for rows owned by lower ranks: one value per remote row
 template <typename V>
 __global__ void __launch_bounds__(256)
@@ -850,6 +864,8 @@ struct cfs_hip_sym_s {
   virtual int rows() = 0;
   virtual int timeline(void *y, const void *x, unsigned long long *host, int cap, int *ngroups) = 0;
   virtual int group_features(long long *out, int cap, int *ngroups) = 0;
+  // values_dev: the caller's full CSR value array (same pattern as at create), on this device
+  virtual int update_values(const void *values_dev, long long nnz, hipStream_t st) = 0;
   int device = 0; // the device this handle's arrays live on (current device at create)
   HostStage stage; // host-pointer callers
   // the last (y, x) pair whose placement was validated (async entry points)
@@ -860,6 +876,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   SymPlan<V> P; // big arrays released after upload
   DevBuf tiles, gfirst, group_ptr, slot_col, rowinfo, diag, slice_meta, leadlane, vals, slots, strip;
   DevBuf cvals, crows, ccols, fvals, frows, fcols;
+  DevBuf val_map, cval_map, fval_map, diag_map; // CFS_HIP_FLAG_KEEP_VALUE_MAP
+  bool has_value_map = false;
+  int64_t nnz_caller = 0; // entries of the caller's CSR the maps point into
   DevBuf fold_rec, fold_idx, send_ptr, send_idx;
   DevBuf rfold_rec, rfold_idx;
   SymDev<V> dev{};
@@ -892,6 +911,17 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(fvals, P.fvals)
     UP(frows, P.frows)
     UP(fcols, P.fcols)
+    has_value_map = !P.val_map.empty();
+    if (has_value_map) {
+      UP(val_map, P.val_map)
+      UP(cval_map, P.cval_map)
+      UP(fval_map, P.fval_map)
+      UP(diag_map, P.diag_map)
+      std::vector<int32_t>().swap(P.val_map);
+      std::vector<int32_t>().swap(P.cval_map);
+      std::vector<int32_t>().swap(P.fval_map);
+      std::vector<int32_t>().swap(P.diag_map);
+    }
     {
       std::vector<int4> rec;
       std::vector<int32_t> rest;
@@ -1085,7 +1115,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
                         (int64_t)P.tiles.size() * (int64_t)sizeof(Tile);
     o->device_bytes = (int64_t)(tiles.bytes + group_ptr.bytes + slot_col.bytes +
                                 rowinfo.bytes + diag.bytes + slice_meta.bytes + leadlane.bytes + vals.bytes + cvals.bytes + crows.bytes + ccols.bytes +
-                                fvals.bytes + frows.bytes + fcols.bytes +
+                                fvals.bytes + frows.bytes + fcols.bytes + val_map.bytes + cval_map.bytes +
+                                fval_map.bytes + diag_map.bytes +
                                 slots.bytes + strip.bytes + fold_rec.bytes +
                                 fold_idx.bytes + send_ptr.bytes + send_idx.bytes);
   }
@@ -1131,6 +1162,27 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
         o[9] += t.nslots;
       }
     }
+    return 0;
+  }
+  int update_values(const void *values_dev, long long nnz, hipStream_t st) override {
+    if (!has_value_map)
+      return set_err(CFS_HIP_ERR_ARG, "handle was created without CFS_HIP_FLAG_KEEP_VALUE_MAP");
+    if (P.deterministic)
+      return set_err(CFS_HIP_ERR_UNSUPPORTED, "deterministic handle: its fixed-point scale depends on the values");
+    if (nnz != nnz_caller) return set_err(CFS_HIP_ERR_ARG, "value count differs from the matrix the handle was built from");
+    const V *src = (const V *)values_dev;
+    auto go = [&](DevBuf &dst, DevBuf &map) {
+      const long long cnt = (long long)(map.bytes / 4);
+      if (cnt <= 0) return;
+      const int grid = (int)std::min<long long>((cnt + 255) / 256, 256 * 16);
+      hipLaunchKernelGGL((cfs_value_scatter_kernel<V>), dim3(grid), dim3(256), 0, st, (V *)dst.p,
+                         (const int32_t *)map.p, src, cnt);
+    };
+    go(vals, val_map);
+    go(cvals, cval_map);
+    go(fvals, fval_map);
+    go(diag, diag_map);
+    HIPCHK(hipGetLastError());
     return 0;
   }
   int n() override { return P.n; }
@@ -1278,6 +1330,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     if (o->flags & CFS_HIP_FLAG_SHARD_EXCHANGE) r.mirror_offblock = false;
     if (o->flags & CFS_HIP_FLAG_HYB) r.hyb = true;
     if (o->flags & CFS_HIP_FLAG_DETERMINISTIC) r.deterministic = true;
+    if (o->flags & CFS_HIP_FLAG_KEEP_VALUE_MAP) r.keep_value_map = true;
   }
   // developer knobs (like CFS_HIP_MAX_SLOTS): far threshold, HYB on / off
   if (const char *e = getenv("CFS_HIP_FAR_USES"))
@@ -1370,6 +1423,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     delete m;
     return set_err(plan_error_code(e), e);
   }
+  m->nnz_caller = rowptr[n];
   rc = m->upload();
   if (rc) {
     delete m;
@@ -1411,6 +1465,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     auto *alt = new SymMatrix<V>();
     alt->value_bytes = (int)sizeof(V);
     alt->device = cur_dev;
+    alt->nnz_caller = rowptr[n];
     float t_def = 0, t_alt = 0;
     bool ok = query_residency<V>(po2) == 0 &&
               cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
@@ -1572,6 +1627,17 @@ struct MultiSym : cfs_hip_sym_s {
   int group_features(long long *, int, int *) override {
     return set_err(CFS_HIP_ERR_ARG, "no group features for a multi-device handle");
   }
+  int update_values(const void *values_dev, long long nnz, hipStream_t st) override {
+    // (values_dev lives on the home device; shards on other devices read it over peer access)
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t g = 0; g < shard.size(); g++) {
+      DeviceGuard dg(dev[g]);
+      int rc = shard[g]->update_values(values_dev, nnz, st_[g]);
+      if (rc) return rc;
+      HIPCHK(hipStreamSynchronize(st_[g]));
+    }
+    return 0;
+  }
   int ngpus() const { return (int)shard.size(); }
 };
 
@@ -1717,6 +1783,37 @@ int cfs_hip_sym_spmv(cfs_hip_sym_t h, void *y, const void *x) {
                     [&](void *yd, const void *xd, hipStream_t st) {
                       return h->spmv_local(yd, xd, nullptr, st);
                     });
+}
+
+// New numeric values, same sparsity pattern (a matrix reassembled in every step of a
+// non-linear solve): the caller's full CSR value array -- host or device pointer -- is
+// poured into the existing schedule by a device kernel; tune() is not repeated.
+static int update_values(cfs_hip_sym_t h, const void *values, long long nnz, size_t vb) {
+  if (!h || !values) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  if ((size_t)h->value_bytes != vb) return set_err(CFS_HIP_ERR_ARG, "value type differs from the handle's");
+  cfs_rt::DevCtx *ctx;
+  int rc = cfs_rt::device_ctx(h->device, &ctx);
+  if (rc) return rc;
+  DeviceGuard g(h->device);
+  const cfs_rt::PtrInfo vi = cfs_rt::classify(values);
+  DevBuf tmp;
+  const void *src = values;
+  if (!vi.device) {
+    if ((rc = tmp.alloc((size_t)nnz * vb))) return rc;
+    HIPCHK(hipMemcpyAsync(tmp.p, values, (size_t)nnz * vb, hipMemcpyHostToDevice, ctx->stream));
+    src = tmp.p;
+  } else if (vi.dev != h->device) {
+    return set_err(CFS_HIP_ERR_ARG, "values live on another device than the matrix");
+  }
+  if ((rc = h->update_values(src, nnz, ctx->stream))) return rc;
+  HIPCHK(hipStreamSynchronize(ctx->stream)); // tmp goes away; later SpMVs on any stream see the values
+  return 0;
+}
+int cfs_hip_sym_update_values_f64(cfs_hip_sym_t h, const double *values, long long nnz) {
+  return update_values(h, values, nnz, 8);
+}
+int cfs_hip_sym_update_values_f32(cfs_hip_sym_t h, const float *values, long long nnz) {
+  return update_values(h, values, nnz, 4);
 }
 
 int cfs_hip_sym_shard_send_counts(cfs_hip_sym_t h, int *send_counts) {
@@ -1882,6 +1979,24 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
       }
     for (char ch : seen_row)
       if (!ch) bad++;
+  }
+  // (1b) CFS_HIP_FLAG_KEEP_VALUE_MAP: every stored value is the caller's value at its
+  // recorded position, and every stored entry has a position
+  if (!P.val_map.empty()) {
+    auto same = [&](const std::vector<V> &arr, const std::vector<int32_t> &map, int64_t *mapped) {
+      for (size_t k = 0; k < map.size() && k < arr.size(); k++) {
+        if (map[k] < 0) continue;
+        (*mapped)++;
+        if (map[k] >= rowptr[n] || memcmp(&arr[k], &values[map[k]], sizeof(V)) != 0) bad++;
+      }
+    };
+    int64_t mv = 0, mc = 0, mf = 0, md = 0;
+    same(P.vals, P.val_map, &mv);
+    same(P.cvals, P.cval_map, &mc);
+    same(P.fvals, P.fval_map, &mf);
+    same(P.diag, P.diag_map, &md);
+    if (mv + mc != P.nnz_low + P.mirror_entries - P.far_entries || mf != 2 * P.far_entries) bad++;
+    if (md > (int64_t)(P.row_end - P.row_begin)) bad++;
   }
   // (2) fold + send indices cover every strip entry exactly once and point at
   // a strip entry whose column is the destination row

@@ -85,6 +85,10 @@ struct Options {
   // bit-reproducible results: the y window takes two 8-byte integer words per slot
   // (fixed-point sums, integer LDS atomics) instead of one fp64 word; no far entries
   bool deterministic = false;
+  // also record, for every stored value of the device format, its position in the caller's
+  // CSR value array: new values of the same sparsity pattern can then be poured into the
+  // existing schedule by a device kernel (cfs_hip_sym_update_values_*) instead of tune()
+  bool keep_value_map = false;
 };
 
 // one tile = one pass of a workgroup through prologue / slices / epilogue
@@ -191,6 +195,9 @@ template <typename V> struct SymPlan {
   std::vector<uint16_t> frows;
   std::vector<int32_t> fcols;
   int64_t far_len = 0, far_entries = 0; // padded length; far nonzeros (each stored twice)
+  // keep_value_map: position in the caller's values[] of every entry of vals / cvals /
+  // fvals / diag (-1: padding, or a missing diagonal)
+  std::vector<int32_t> val_map, cval_map, fval_map, diag_map;
   // halo fold (destinations inside [row_begin,row_end)), local row indices
   std::vector<int32_t> fold_row, fold_ptr, fold_idx;
   // remote contributions (destinations < row_begin), global row indices
@@ -323,6 +330,7 @@ template <typename V> struct Builder {
   const int nranks, rank;
   const Options &opt;
   const std::vector<int32_t> *chunks_in, *perm_in;
+  const int32_t *srcpos; // schedule-space entry -> position in the caller's values[] (NULL: identity)
   SymPlan<V> &P;
   int rb = 0, re = 0, rows = 0;
   bool mirror = false;
@@ -344,9 +352,9 @@ template <typename V> struct Builder {
 
   Builder(int n_, const int *rp, const int *ci, const V *va, int nranks_, int rank_,
           const Options &o, const std::vector<int32_t> *chunks, const std::vector<int32_t> *perm,
-          SymPlan<V> &plan)
+          const int32_t *src, SymPlan<V> &plan)
       : n(n_), rowptr(rp), colind(ci), values(va), nranks(nranks_), rank(rank_), opt(o),
-        chunks_in(chunks), perm_in(perm), P(plan) {}
+        chunks_in(chunks), perm_in(perm), srcpos(src), P(plan) {}
 
   bool is_far(int64_t j) const { return !farbits.empty() && ((farbits[j >> 6] >> (j & 63)) & 1); }
   // which entries of row i does the schedule store?  The strict lower triangle,
@@ -375,6 +383,22 @@ template <typename V> struct Builder {
 #pragma omp atomic write
     mirror_fail = true; // structurally unsymmetric input
     return V(0);
+  }
+  // ... and where that value sits in the caller's values[] (keep_value_map)
+  int32_t src_at(int i, int j) const {
+    if (srcpos) return srcpos[j];
+    const int c = colind[j];
+    if (!mirror || c < re) return j;
+    int b = rowptr[c], e = rowptr[c + 1], l = b, r = e;
+    while (l < r) {
+      int m = (l + r) >> 1;
+      if (colind[m] < i) l = m + 1;
+      else r = m;
+    }
+    if (l < e && colind[l] == i) return l;
+    for (int q = b; q < e; q++)
+      if (colind[q] == i) return q;
+    return -1;
   }
 
   bool setup(const int *row_splits_in) {
@@ -873,6 +897,12 @@ template <typename V> struct Builder {
     P.fvals.assign((size_t)P.far_len + 256, V(0));
     P.frows.assign((size_t)P.far_len + 256, 0);
     P.fcols.assign((size_t)P.far_len + 256, 0);
+    if (opt.keep_value_map) {
+      P.val_map.assign((size_t)off + 256, -1);
+      P.cval_map.assign((size_t)coo + 256, -1);
+      P.fval_map.assign((size_t)P.far_len + 256, -1);
+      P.diag_map.assign((size_t)nvr + 1, -1);
+    }
     return true;
   }
 
@@ -883,7 +913,9 @@ template <typename V> struct Builder {
     struct FarE {
       int32_t r, c; // own local row, ORIGINAL global column
       V v;
+      int32_t src; // position of the value in the caller's values[]
     };
+    const bool keep = opt.keep_value_map;
     // the mirrored (upper) ends of the far entries are found from the lower side:
     // a cursor per tile, filled in parallel, sorted afterwards for a fixed order
     std::vector<std::vector<FarE>> far_up(farbits.empty() ? 0 : T);
@@ -897,7 +929,7 @@ template <typename V> struct Builder {
           if (!is_far(j)) continue;
           const int c = colind[j], tc = tile_of_row[c - rb];
           const int at = __atomic_fetch_add(&cur[tc], 1, __ATOMIC_RELAXED);
-          far_up[tc][at] = FarE{c - P.tiles[tc].row0, orig(i), values[j]};
+          far_up[tc][at] = FarE{c - P.tiles[tc].row0, orig(i), values[j], keep ? src_at(i, j) : -1};
         }
     }
 #pragma omp parallel num_threads(host_threads())
@@ -964,10 +996,15 @@ template <typename V> struct Builder {
             amax = std::max(amax, v.a);
             P.rowinfo[t.vrow_off + p0 + l] = (uint32_t)v.r | ((uint32_t)v.a << 16);
             V d = V(0);
+            int dj = -1;
             if (v.k0 == 0)
               for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
-                if (colind[j] == i) d = values[j]; // last duplicate wins, like :1292
+                if (colind[j] == i) {
+                  d = values[j]; // last duplicate wins, like :1292
+                  dj = j;
+                }
             P.diag[t.vrow_off + p0 + l] = d;
+            if (keep && dj >= 0) P.diag_map[t.vrow_off + p0 + l] = srcpos ? srcpos[dj] : dj;
             amax_t = std::max(amax_t, std::fabs((double)d));
           }
           const SliceMeta &sm = P.slice_meta[t.slice_base + s];
@@ -984,6 +1021,8 @@ template <typename V> struct Builder {
                 int q = low[l][(vr[p0 + l].k0 + g) * kPacket + j];
                 const V av = val_at(t.row0 + vr[p0 + l].r, q);
                 tv[o + packet_val_pos<V>(l, j, cnt)] = av;
+                if (keep)
+                  P.val_map[t.nnz_off + o + packet_val_pos<V>(l, j, cnt)] = src_at(t.row0 + vr[p0 + l].r, q);
                 amax_t = std::max(amax_t, std::fabs((double)av));
                 if (is_leader) ts[os + packet_slot_pos(lead, j)] = slot_of(colind[q]);
               }
@@ -1007,6 +1046,7 @@ template <typename V> struct Builder {
               int l = (int)((e & 255) >> 2), j = (int)(e & 3);
               const V av = val_at(t.row0 + r, q);
               cv[pk * 256 + packet_val_pos<V>(l, j)] = av;
+              if (keep) P.cval_map[t.coo_off + pk * 256 + packet_val_pos<V>(l, j)] = src_at(t.row0 + r, q);
               amax_t = std::max(amax_t, std::fabs((double)av));
               cr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)r;
               cc[pk * 256 + packet_slot_pos(l, j)] = slot_of(colind[q]);
@@ -1022,7 +1062,7 @@ template <typename V> struct Builder {
           for (int r = 0; r < t.nown; r++) {
             const int i = t.row0 + r;
             for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
-              if (is_far(j)) fl.push_back(FarE{r, orig(colind[j]), values[j]});
+              if (is_far(j)) fl.push_back(FarE{r, orig(colind[j]), values[j], keep ? src_at(i, j) : -1});
           }
           if ((int)fl.size() != t.nfar_low) bad = true;
           std::vector<FarE> &up = far_up[ti];
@@ -1038,6 +1078,7 @@ template <typename V> struct Builder {
             const int64_t pk = (int64_t)e >> 8;
             const int l = (int)((e & 255) >> 2), j = (int)(e & 3);
             fv[pk * 256 + packet_val_pos<V>(l, j)] = fl[e].v;
+            if (keep) P.fval_map[t.far_off + pk * 256 + packet_val_pos<V>(l, j)] = fl[e].src;
             amax_t = std::max(amax_t, std::fabs((double)fl[e].v));
             fr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)fl[e].r;
             fc[pk * 256 + packet_slot_pos(l, j)] = fl[e].c;
@@ -1195,8 +1236,9 @@ template <typename V>
 bool build_plan_core(int n, const int *rowptr, const int *colind, const V *values,
                      int nranks, int rank, const int *row_splits_in,
                      const Options &opt, const std::vector<int32_t> *chunks_in,
-                     const std::vector<int32_t> *perm_in, SymPlan<V> &P, bool cut_only = false) {
-  Builder<V> b(n, rowptr, colind, values, nranks, rank, opt, chunks_in, perm_in, P);
+                     const std::vector<int32_t> *perm_in, SymPlan<V> &P, bool cut_only = false,
+                     const int32_t *srcpos = nullptr) {
+  Builder<V> b(n, rowptr, colind, values, nranks, rank, opt, chunks_in, perm_in, srcpos, P);
   return b.run(row_splits_in, cut_only);
 }
 
@@ -1382,6 +1424,7 @@ template <typename V> struct ScheduleSpace {
   int rb = 0, re = 0, nchunks = 0;
   std::vector<int32_t> perm, chunk, brp, bci;
   std::vector<V> bva;
+  std::vector<int32_t> bsr; // keep_value_map: entry -> position in the caller's values[]
 };
 
 // Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the full
@@ -1434,7 +1477,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     for (int g = 0; g <= nchunks; g++) merged[g] = sp.chunk[2 * g];
     pt.lap("schedule space reused");
     if (build_plan_core<V>(n, sp.brp.data(), sp.bci.data(), sp.bva.data(), nranks, rank,
-                           row_splits_in, opt, &merged, &sp.perm, P))
+                           row_splits_in, opt, &merged, &sp.perm, P, false,
+                           sp.bsr.empty() ? nullptr : sp.bsr.data()))
       return true;
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
                               nullptr, nullptr, P);
@@ -1483,10 +1527,18 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   std::vector<V> &bva = sp.bva;
   bci.assign((size_t)bnnz + 1, 0);
   bva.assign((size_t)bnnz + 1, V(0));
+  std::vector<int32_t> &bsr = sp.bsr;
+  bsr.clear();
+  if (opt.keep_value_map) bsr.assign((size_t)bnnz + 1, -1);
   bool asym = false;
 #pragma omp parallel num_threads(host_threads())
   {
-    std::vector<std::pair<int32_t, V>> tmp;
+    struct Ent {
+      int32_t first;
+      V second;
+      int32_t src;
+    };
+    std::vector<Ent> tmp;
 #pragma omp for schedule(dynamic, 256)
     for (int p = rb; p < re; p++) {
       const int i = perm[p - rb];
@@ -1507,12 +1559,10 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
             src = j;
           }
         }
-        tmp.push_back({col, values[src]});
+        tmp.push_back(Ent{col, values[src], src});
       }
       std::stable_sort(tmp.begin(), tmp.end(),
-                       [](const std::pair<int32_t, V> &x, const std::pair<int32_t, V> &y) {
-                         return x.first < y.first;
-                       });
+                       [](const Ent &x, const Ent &y) { return x.first < y.first; });
       int q = brp[p];
       for (size_t k = 0; k < tmp.size(); k++) {
         // duplicate entries (the reader keeps them) cannot be paired with their
@@ -1523,6 +1573,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
         }
         bci[q] = tmp[k].first;
         bva[q] = tmp[k].second;
+        if (!bsr.empty()) bsr[q] = tmp[k].src;
         q++;
       }
     }
@@ -1574,7 +1625,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   }
   if (use_clustered &&
       build_plan_core<V>(n, brp.data(), bci.data(), bva.data(), nranks, rank, row_splits_in, opt,
-                         &chunk, &perm, P)) {
+                         &chunk, &perm, P, false, bsr.empty() ? nullptr : bsr.data())) {
     sp.valid = true; // a later build with half as many chunks may reuse it
     sp.rb = rb;
     sp.re = re;
@@ -1583,6 +1634,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   }
   std::vector<int32_t>().swap(bci);
   std::vector<V>().swap(bva);
+  std::vector<int32_t>().swap(bsr);
   return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
                             nullptr, P);
 }

@@ -52,6 +52,7 @@ def _stream_ptr(stream=None):
 
 
 FLAG_SHARD_EXCHANGE = 64  # include/cfs_hip.h: CFS_HIP_FLAG_SHARD_EXCHANGE
+FLAG_KEEP_VALUE_MAP = 2048  # CFS_HIP_FLAG_KEEP_VALUE_MAP
 
 
 def make_options(max_slots=0, max_tile_nnz=0, block_threads=0, flags=0):
@@ -216,6 +217,17 @@ class SymMatrix:
         _lib.check(_lib.load().cfs_hip_sym_recv_fold_async(
             self._h, _ptr(y_block), _ptr(recv_buf) if recv_buf is not None else None,
             _stream_ptr(stream)))
+
+    def update_values(self, values):
+        """new values, same sparsity pattern (numpy array or device tensor in the order of the
+        CSR the matrix was created from); needs FLAG_KEEP_VALUE_MAP at construction"""
+        suf = "f64" if self.dtype == np.float64 else "f32"
+        if isinstance(values, np.ndarray):
+            values = np.ascontiguousarray(values, dtype=self.dtype)
+            ptr, cnt = values.ctypes.data, values.size
+        else:
+            ptr, cnt = values.data_ptr(), values.numel()
+        _lib.check(getattr(_lib.load(), "cfs_hip_sym_update_values_" + suf)(self._h, ptr, cnt))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

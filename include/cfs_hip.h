@@ -134,6 +134,10 @@ typedef struct {
  * Costs LDS (24 instead of 16 bytes per slot: smaller tiles) and ALU; no far entries,
  * 512-thread workgroups only.  Same tolerance against the oracle as the default.   */
 #define CFS_HIP_FLAG_DETERMINISTIC 1024
+/* keep, for every stored value of the device format, its position in the caller's CSR
+ * value array (4 bytes per stored nonzero of device memory): cfs_hip_sym_update_values_*
+ * can then refresh the numbers of the matrix without repeating tune()             */
+#define CFS_HIP_FLAG_KEEP_VALUE_MAP 2048
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->
@@ -184,6 +188,16 @@ int cfs_hip_sym_num_gpus(cfs_hip_sym_t h, int *ngpus); /* shards of the handle (
 int cfs_hip_sym_balanced_splits(int n, const int *rowptr, const int *colind,
                                 int nranks, int *row_splits);
 int cfs_hip_sym_destroy(cfs_hip_sym_t h);
+/* New values, SAME sparsity pattern (a stiffness matrix reassembled in every Newton step;
+ * the reference would run tune() -- split, conflict graph, colouring,
+ * csr_matrix.tpp:1204-1639 -- again): `values` is the full CSR value array in the order
+ * of the rowptr / colind the handle was created from, nnz entries, host or device
+ * pointer.  A device kernel pours it into the existing schedule (the value half of
+ * tune()'s packing, on the GPU); tiles, slots, fold index stay.  The handle must have
+ * been created with CFS_HIP_FLAG_KEEP_VALUE_MAP; returns after the new values are in
+ * place.  Not for CFS_HIP_FLAG_DETERMINISTIC handles (their scale depends on the values). */
+int cfs_hip_sym_update_values_f64(cfs_hip_sym_t h, const double *values, long long nnz);
+int cfs_hip_sym_update_values_f32(cfs_hip_sym_t h, const float *values, long long nnz);
 
 /* ---- dense_vector_multiply (replaces spmv_fn = cpu_mv_sym_conflict_free_v2,
  *      csr_matrix.tpp:2965-3028).  y is fully overwritten (the reference test

@@ -88,6 +88,21 @@ def test_hyb_schedules_encode_the_lower_triangle(name, scale, flags):
     assert rep["far_entries"] >= 0 and rep["halo_slots"] <= 1.02 * base["halo_slots"] + 64
 
 
+@pytest.mark.parametrize("flags", [0, FLAG_NO_REORDER, FLAG_HYB, FLAG_CLUSTER | FLAG_HYB])
+@pytest.mark.parametrize("name,scale", [("Flan_1565", 0.05), ("ldoor", 0.1), ("pdb1HYS", 0.3)])
+def test_value_map_points_at_the_callers_values(name, scale, flags):
+    """CFS_HIP_FLAG_KEEP_VALUE_MAP (2048): cfs_hip_sym_plan_check_* verifies that every
+    stored value of the device format equals the caller's value at its recorded position
+    (what cfs_hip_sym_update_values_* relies on), whole matrix and mirrored shards"""
+    n, rp, ci, va, low = synth.generate(name, scale)
+    rep = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(flags=flags | 2048))
+    assert rep["mismatches"] == 0 and rep["decoded"] == low
+    rs = cfs.balanced_splits(n, rp, ci, 3)
+    for r in range(3):
+        rep = cfs.plan_check(n, rp, ci, va, 3, r, rs, options=cfs.make_options(flags=flags | 2048))
+        assert rep["mismatches"] == 0
+
+
 def test_hyb_takes_the_single_use_halo_columns_out():
     """ldoor stand-in: 2 % fat rows scatter single entries over a 40 000-row window;
     each of them costs a halo slot (slot table, x gather, strip, fold) for one nonzero"""

@@ -345,3 +345,51 @@ def test_unstructured_stand_in_parity(name):
         assert scaled_err(_spmv(A, x, torch), y_ld, absrow) <= 1e-12
         assert A.stats()["nnz_low"] == low
         A.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("name,scale,flags", [("Flan_1565", 0.05, 0), ("Flan_1565", 0.05, FLAG_NO_REORDER),
+                                              ("ldoor", 0.15, FLAG_HYB), ("pdb1HYS", 0.5, FLAG_HYB | FLAG_CLUSTER)])
+def test_update_values_refreshes_the_schedule_on_the_device(name, scale, flags, dtype):
+    """cfs_hip_sym_update_values_*: new numbers, same sparsity pattern, poured into the
+    existing schedule by a device kernel (no second tune()); host and device pointers"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from oracle import oracle
+    torch = _torch()
+    n, rp, ci, va, _ = synth.generate(name, scale)
+    va = va.astype(dtype)
+    x = np.random.default_rng(2).uniform(-1, 1, n).astype(dtype)
+    A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=flags | FLAG_NO_CAL | cfs.FLAG_KEEP_VALUE_MAP))
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(_spmv(A, x, torch), y_ld, absrow) <= TOL[dtype]
+    # a symmetric perturbation of every value: v -> v * f(min(i, j), max(i, j)) + g
+    rows = np.repeat(np.arange(n), np.diff(rp))
+    lo, hi = np.minimum(rows, ci), np.maximum(rows, ci)
+    va2 = (va.astype(np.float64) * (0.5 + ((lo * 31 + hi * 17) % 13) / 13.0) + 0.125 * ((lo + hi) % 3)).astype(dtype)
+    y2_ld, absrow2 = oracle.csr_spmv_ld(n, rp, ci, va2, x)
+    A.update_values(va2)                                   # host pointer
+    assert scaled_err(_spmv(A, x, torch), y2_ld, absrow2) <= TOL[dtype]
+    A.update_values(torch.from_numpy(va).cuda())           # device pointer: back to the first values
+    assert scaled_err(_spmv(A, x, torch), y_ld, absrow) <= TOL[dtype]
+    A.close()
+    B = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=flags | FLAG_NO_CAL))
+    from cfs_spmv_amd import _lib
+    with pytest.raises(_lib.CfsHipError, match="KEEP_VALUE_MAP"):
+        B.update_values(va2)
+    B.close()
+
+
+def test_update_values_on_a_multi_device_handle_and_mirrored_shards():
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from oracle import oracle
+    torch = _torch()
+    n, rp, ci, va, _ = synth.generate("Flan_1565", 0.03)
+    x = synth.make_x(n)
+    A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=cfs.FLAG_KEEP_VALUE_MAP), ngpus=3)
+    va2 = va * 0.75
+    A.update_values(va2)
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va2, x)
+    assert scaled_err(_spmv(A, x, torch), y_ld, absrow) <= 1e-12
+    A.close()
