@@ -455,9 +455,12 @@ def main():
             key = f"{args.matrix}:{args.scale}:{args.dtype}:{N}"
             if args.shard_of > 1:
                 key += f":shard{args.shard_rank}of{args.shard_of}"
-            ent = tj.get(key, {})
-            same = all(ent.get(k) == st[k] for k in ("bytes_streamed", "lds_bytes", "block_threads"))
-            traffic = ent.get("hbm_bytes_per_launch") if same else None
+            # (tune() keeps the faster of two window shapes, and boxes differ: a workload
+            # may hold one entry per schedule it was profiled on)
+            ents = tj.get(key, [])
+            for ent in (ents if isinstance(ents, list) else [ents]):
+                if all(ent.get(k) == st[k] for k in ("bytes_streamed", "lds_bytes", "block_threads")):
+                    traffic = ent.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 

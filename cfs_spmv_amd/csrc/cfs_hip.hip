@@ -1480,7 +1480,10 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     if (getenv("CFS_PLAN_VERBOSE"))
       fprintf(stderr, "[cfs_hip] %s: current %.1f us, alternative %.1f us%s\n", what, t_def * 100.0,
               t_alt * 100.0, ok ? "" : " (alternative not built)");
-    if (ok && t_alt < 0.99f * t_def) {
+    // (CFS_HIP_KEEP_ALT=1: developer knob -- keep the alternative whatever the clock says,
+    // so that each of the schedules tune() may end up with can be profiled on any box)
+    const char *force = getenv("CFS_HIP_KEEP_ALT");
+    if (ok && (t_alt < 0.99f * t_def || (force && atoi(force) != 0))) {
       delete m;
       m = alt;
       po = po2;

@@ -1,2 +1,4 @@
-for cfg in "0 0" "4992 1024" "9984 1024" "2496 256" "1280 256" "2496 512"; do set -- $cfg; echo "slots $1 block $2: $(SB_SLOTS=$1 SB_BLOCK=$2 python tools/shard_bench.py Flan_1565 1.0 8 3 2>&1 | tail -1 | cut -c90-330)"; done
-for cfg in "0 0" "4992 1024" "2496 256" ; do set -- $cfg; echo "pwtk slots $1 block $2: $(python tools/quick_bench.py pwtk 1.0 $1,$2,0,32 2>&1 | grep cfg | cut -c1-200)"; done
+mkdir -p gpurun_out/r02
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python -m pytest tests -m gpu -x -q > gpurun_out/r02/t_final.log 2>&1; tail -2 gpurun_out/r02/t_final.log
+python bench.py > gpurun_out/r02/bench_default.json 2> gpurun_out/r02/bench_default.err; tail -c 900 gpurun_out/r02/bench_default.json

@@ -1,7 +1,8 @@
 """copy the per-config evidence of tools/profile_round.sh from gpurun_out/<round>/<cfg>/ into
 profiles/<round>_<cfg>_* (tracked) and rebuild profiles/hbm_traffic.json, the table bench.py
 reads for roofline.traffic (keyed by workload, validated against the schedule that runs).
-usage: collect_profiles.py r02 flan=Flan_1565:1.0:f64:1 pwtk=pwtk:1.0:f64:1 ..."""
+usage: collect_profiles.py r02 flan=Flan_1565:1.0:f64:1 flan_w1024=Flan_1565:1.0:f64:1 pwtk=pwtk:1.0:f64:1 ...
+(several sets may share a key: one entry per schedule the workload was profiled on)"""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1]
@@ -13,7 +14,7 @@ for arg in sys.argv[2:]:
     for name in ("bench.json", "kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "hbm_traffic.json"):
         shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_{name}"))
     t = json.load(open(os.path.join(src, "hbm_traffic.json")))
-    table[key] = {
+    table.setdefault(key, []).append({
         "hbm_bytes_per_launch": t["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"],
         "kernel": "cfs_sym_tile_kernel",
         # the schedule the counters were taken on: bench.py quotes the number only for the same
@@ -22,6 +23,6 @@ for arg in sys.argv[2:]:
         "source": f"profiles/{rnd}_{cfg}_pmc_fetch.csv + _pmc_write.csv (rocprofv3 --pmc FETCH_SIZE / "
                   "WRITE_SIZE, separate passes); reads = 2 x FETCH_SIZE KiB (gfx950 correction), "
                   "writes = WRITE_SIZE KiB",
-    }
+    })
 json.dump(table, open(table_path, "w"), indent=1)
 print(json.dumps(table, indent=1))
