@@ -1,4 +1,3 @@
-mkdir -p gpurun_out/r02
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
-python -m pytest tests -m gpu -x -q > gpurun_out/r02/t_final.log 2>&1; tail -2 gpurun_out/r02/t_final.log
-python bench.py > gpurun_out/r02/bench_default.json 2> gpurun_out/r02/bench_default.err; tail -c 900 gpurun_out/r02/bench_default.json
+for b in 4096 2048 8192; do for m in Flan_1565 ldoor; do echo "csr block $b $m: $(CFS_HIP_CSR_BLOCK=$b QB_CSR=1 python tools/quick_bench.py $m 1.0 0,0,0,32 2>&1 | grep '"csr"')"; done; done
+echo "f32 queen: $(QB_DTYPE=f32 QB_CSR=1 python tools/quick_bench.py Queen_4147 1.0 0,0,0,32 2>&1 | grep '"csr"')"
+python -m pytest tests/test_gpu_parity.py -m gpu -q -k csr 2>&1 | tail -1
