@@ -154,9 +154,11 @@ static int make_spec(const char *name, double scale, spec_t *sp) {
     sp->n = (int)(217918 * scale);
     sp->dof = 2; sp->pts = 27;
     sp->nx = (int)ceil(48 * s3); sp->ny = (int)ceil(48 * s3); sp->nz = (int)ceil(48 * s3);
-  } else if (!strcmp(name, "ldoor")) {
+  } else if (!strcmp(name, "ldoor") || !strcmp(name, "ldoor_regular")) {
+    /* "ldoor_regular": the same 7-point x 7-dof grid without the fat / thin rows (what is
+     * left of the ldoor stand-in once its single-use entries are far entries) */
     sp->n = (int)(952203 * scale);
-    sp->dof = 7; sp->pts = 7; sp->irregular = 1;
+    sp->dof = 7; sp->pts = 7; sp->irregular = strcmp(name, "ldoor") == 0;
     sp->nx = (int)ceil(52 * s3); sp->ny = (int)ceil(52 * s3); sp->nz = (int)ceil(51 * s3);
   } else if (!strcmp(name, "Flan_1565")) {
     sp->n = (int)(1564794 * scale);
