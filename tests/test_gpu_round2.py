@@ -393,3 +393,37 @@ def test_update_values_on_a_multi_device_handle_and_mirrored_shards():
     y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va2, x)
     assert scaled_err(_spmv(A, x, torch), y_ld, absrow) <= 1e-12
     A.close()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_deterministic_mirrored_shards(dtype):
+    """the deterministic y window in the shard instantiation of the kernel (one-sided
+    off-block slots): every rank's block is bit-reproducible and within tolerance"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import _lib, synth
+    from oracle import oracle
+    torch = _torch()
+    n, rp, ci, va, _ = synth.generate("Flan_1565", 0.03)
+    va = va.astype(dtype)
+    x = np.random.default_rng(8).uniform(-1, 1, n).astype(dtype)
+    xd = torch.from_numpy(x).cuda()
+    rs = cfs.balanced_splits(n, rp, ci, 3)
+    y = np.zeros(n, dtype=dtype)
+    for r in range(3):
+        A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=FLAG_DET | FLAG_NO_CAL),
+                          row_splits=rs, rank=r)
+        outs = []
+        for k in range(3):
+            yb = torch.full((int(rs[r + 1] - rs[r]),), float(k), dtype=xd.dtype, device="cuda")
+            A.spmv_phases(yb, xd, None, 3)
+            torch.cuda.synchronize()
+            outs.append(yb.cpu().numpy())
+        assert np.array_equal(outs[0].view(np.uint8), outs[1].view(np.uint8))
+        assert np.array_equal(outs[0].view(np.uint8), outs[2].view(np.uint8))
+        y[rs[r]:rs[r + 1]] = outs[0]
+        if r == 0:  # a deterministic handle keeps no value map semantics: refused, not mangled
+            with pytest.raises(_lib.CfsHipError):
+                A.update_values(va)
+        A.close()
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
