@@ -15,12 +15,20 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("pdb1HYS", np.float64), ("pwtk", np.float64), ("ldoor", np.float64),
-         ("Flan_1565", np.float64), ("Queen_4147", np.float32)]
+FLAG_HYB, FLAG_DET = 128, 1024  # include/cfs_hip.h: CFS_HIP_FLAG_HYB, CFS_HIP_FLAG_DETERMINISTIC
+
+# (stand-in, dtype, mode): "" = what tune() picks; "hyb" = far entries forced on;
+# "det" = fixed-point accumulation; "x4" = one handle over four mirrored shards
+# (cfs_hip_sym_create_multi_*, all on this box's one GPU)
+CASES = [("pdb1HYS", np.float64, ""), ("pwtk", np.float64, ""), ("ldoor", np.float64, ""),
+         ("Flan_1565", np.float64, ""), ("Queen_4147", np.float32, ""),
+         ("unstruct", np.float64, ""), ("ldoor", np.float64, "hyb"),
+         ("Flan_1565", np.float64, "det"), ("Queen_4147", np.float32, "det"),
+         ("Flan_1565", np.float64, "x4")]
 
 
-@pytest.mark.parametrize("name,dtype", CASES, ids=[c[0] for c in CASES])
-def test_full_size_properties(name, dtype):
+@pytest.mark.parametrize("name,dtype,mode", CASES, ids=["-".join(filter(None, (c[0], c[2]))) for c in CASES])
+def test_full_size_properties(name, dtype, mode):
     import torch
     import cfs_spmv_amd as cfs
     from cfs_spmv_amd import synth
@@ -29,9 +37,27 @@ def test_full_size_properties(name, dtype):
     tdt = torch.float64 if dtype == np.float64 else torch.float32
     n, rp, ci, va, low = synth.generate(name, 1.0)
     va = va.astype(dtype, copy=False)
-    A = cfs.SymMatrix(n, rp, ci, va)
+    if mode == "x4":
+        A = cfs.SymMatrix(n, rp, ci, va, ngpus=4, devices=[0, 0, 0, 0])
+    else:
+        flags = {"": 0, "hyb": FLAG_HYB, "det": FLAG_DET}[mode]
+        A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=flags) if flags else None)
     st = A.stats()
-    assert st["nnz_low"] == low and st["nnz_full"] == rp[-1]
+    assert st["nnz_full"] == rp[-1]
+    if mode != "x4":
+        assert st["nnz_low"] == low
+    if mode == "hyb":
+        assert st["far_entries"] > 0
+    if mode == "det":
+        # fixed-point accumulation carries 2^-67 of the tile's scale per product
+        # (DESIGN.md section 2): the fp32 / fp64 tolerances below hold unchanged
+        y0 = torch.full((n,), float("nan"), dtype=tdt, device="cuda")
+        y1 = y0.clone()
+        xs = torch.linspace(-1, 1, n, dtype=tdt, device="cuda")
+        A.dense_vector_multiply(y0, xs)
+        A.dense_vector_multiply(y1, xs)
+        assert torch.equal(y0.view(torch.int64 if dtype == np.float64 else torch.int32),
+                           y1.view(torch.int64 if dtype == np.float64 else torch.int32))
     G = cfs.CsrMatrix(n, n, rp, ci, va)
     # |A| |x| scale from the CSR kernel on absolute values
     Gabs = cfs.CsrMatrix(n, n, rp, ci, np.abs(va))
