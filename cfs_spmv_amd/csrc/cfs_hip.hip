@@ -917,7 +917,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
       UP(cval_map, P.cval_map)
       UP(fval_map, P.fval_map)
       UP(diag_map, P.diag_map)
-      std::vector<int32_t>().swap(P.val_map);
+      cfs_plan::release_async(P.val_map);
       std::vector<int32_t>().swap(P.cval_map);
       std::vector<int32_t>().swap(P.fval_map);
       std::vector<int32_t>().swap(P.diag_map);
@@ -967,8 +967,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     // the stream is cacheable across SpMVs only if it fits the 256 MiB Infinity Cache
     nt_stream = (stream_len * (int64_t)sizeof(V) + slot_len * 2) > (int64_t)240 * 1024 * 1024;
     // release the big host arrays; keep the small metadata
-    std::vector<V>().swap(P.vals);
-    std::vector<uint16_t>().swap(P.slots);
+    cfs_plan::release_async(P.vals);
+    cfs_plan::release(P.slots);
     std::vector<uint8_t>().swap(P.leadlane);
     std::vector<V>().swap(P.cvals);
     std::vector<uint16_t>().swap(P.crows);
@@ -1401,6 +1401,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   if (nranks < 1 || rank < 0 || rank >= nranks)
     return set_err(CFS_HIP_ERR_ARG, "bad rank / nranks");
   if (nranks > 1 && !row_splits) return set_err(CFS_HIP_ERR_ARG, "row_splits required");
+  cfs_plan::PhaseTimer ct;
   int rc = ensure_init();
   if (rc) return rc;
   int cur_dev = 0;
@@ -1413,6 +1414,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     delete m;
     return rc;
   }
+  ct.lap("create: runtime + kernel residency");
   // kept until the window-shape step below has had its chance to reuse it
   cfs_plan::ScheduleSpace<V> space;
   const bool want_tuning = !(opt && (opt->flags & CFS_HIP_FLAG_NO_CALIBRATE));
@@ -1424,7 +1426,9 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     return set_err(plan_error_code(e), e);
   }
   m->nnz_caller = rowptr[n];
+  ct.lap("create: build_plan");
   rc = m->upload();
+  ct.lap("create: upload");
   if (rc) {
     delete m;
     return rc;
@@ -1504,7 +1508,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
       return rc;
     }
   }
-  space = cfs_plan::ScheduleSpace<V>(); // release the schedule-space matrix
+  space.drop(); // release the schedule-space matrix
   // ---- HYB by measurement (Format::sss, Tuning::Aggressive) --------------------------
   // A halo column that its tile uses once costs a slot, a slot-table entry, an x
   // gather, a strip store and a fold entry for one nonzero; as a FAR entry the nonzero
@@ -1522,6 +1526,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   }
   m->ablate_mode = opt ? (opt->flags & CFS_HIP_FLAG_ABLATE_MASK) : 0;
   *out = m;
+  ct.lap("create: measured alternatives");
   return 0;
 }
 
@@ -1986,7 +1991,7 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
   // (1b) CFS_HIP_FLAG_KEEP_VALUE_MAP: every stored value is the caller's value at its
   // recorded position, and every stored entry has a position
   if (!P.val_map.empty()) {
-    auto same = [&](const std::vector<V> &arr, const std::vector<int32_t> &map, int64_t *mapped) {
+    auto same = [&](const auto &arr, const auto &map, int64_t *mapped) {
       for (size_t k = 0; k < map.size() && k < arr.size(); k++) {
         if (map[k] < 0) continue;
         (*mapped)++;

@@ -54,6 +54,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace cfs_plan {
@@ -159,6 +160,43 @@ inline int host_threads() {
   return cached;
 }
 
+// The arrays that hold one entry per stored nonzero (hundreds of MB): a vector
+// whose resize() does NOT touch the memory, filled by all host threads.  A
+// std::vector would zero 0.7 GB of fresh pages from one thread first -- half of
+// tune()'s host time went into those page faults.
+template <typename T> struct NoInitAlloc : std::allocator<T> {
+  template <typename U> struct rebind {
+    using other = NoInitAlloc<U>;
+  };
+  NoInitAlloc() = default;
+  template <typename U> NoInitAlloc(const NoInitAlloc<U> &) {}
+  template <typename U> void construct(U *p) { ::new ((void *)p) U; } // default-init: no store
+  template <typename U, typename A0, typename... A> void construct(U *p, A0 &&a0, A &&...a) {
+    ::new ((void *)p) U(std::forward<A0>(a0), std::forward<A>(a)...);
+  }
+};
+template <typename T> using BigVec = std::vector<T, NoInitAlloc<T>>;
+template <typename T> inline void release(BigVec<T> &v) { BigVec<T>().swap(v); }
+// ... and handing hundreds of MB back to the kernel takes tens of milliseconds: a
+// big array that is no longer needed is freed by a thread of its own
+template <typename T> inline void release_async(BigVec<T> &v) {
+  if (v.capacity() * sizeof(T) < ((size_t)64 << 20)) return release(v);
+  auto *h = new BigVec<T>();
+  h->swap(v);
+  std::thread([h] { delete h; }).detach();
+}
+// v = n copies of val, pages first touched (and filled) by all host threads
+template <typename T> inline void par_assign(BigVec<T> &v, size_t n, T val) {
+  v.clear();
+  v.resize(n);
+  T *p = v.data();
+  const size_t chunk = (size_t)1 << 18;
+  const int64_t nch = (int64_t)((n + chunk - 1) / chunk);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+  for (int64_t c = 0; c < nch; c++)
+    std::fill(p + (size_t)c * chunk, p + std::min(n, (size_t)(c + 1) * chunk), val);
+}
+
 template <typename V> struct SymPlan {
   // problem
   int n = 0, row_begin = 0, row_end = 0, nranks = 1, rank = 0;
@@ -183,8 +221,8 @@ template <typename V> struct SymPlan {
   std::vector<V> diag;              // [nvrows] diagonal (first chunk of a row only)
   int64_t nvrows = 0;
   std::vector<SliceMeta> slice_meta; // [S]
-  std::vector<V> vals;              // [stream_len + pad] packet stream
-  std::vector<uint16_t> slots;      // [slot_len + pad]: only the leader lanes' slots
+  BigVec<V> vals;                   // [stream_len + pad] packet stream
+  BigVec<uint16_t> slots;           // [slot_len + pad]: only the leader lanes' slots
   std::vector<uint8_t> leadlane;    // [S * 64 + pad] lane -> its leader lane in the slice
   int64_t slot_len = 0;
   std::vector<V> cvals;             // [coo_len] COO leftovers, packet layout
@@ -197,7 +235,8 @@ template <typename V> struct SymPlan {
   int64_t far_len = 0, far_entries = 0; // padded length; far nonzeros (each stored twice)
   // keep_value_map: position in the caller's values[] of every entry of vals / cvals /
   // fvals / diag (-1: padding, or a missing diagonal)
-  std::vector<int32_t> val_map, cval_map, fval_map, diag_map;
+  BigVec<int32_t> val_map;
+  std::vector<int32_t> cval_map, fval_map, diag_map;
   // halo fold (destinations inside [row_begin,row_end)), local row indices
   std::vector<int32_t> fold_row, fold_ptr, fold_idx;
   // remote contributions (destinations < row_begin), global row indices
@@ -889,8 +928,8 @@ template <typename V> struct Builder {
     P.coo_len = coo;
     // one packet of padding: the kernel prefetches a slice's first packet with
     // every lane before it knows how many lanes the packet really has
-    P.vals.assign((size_t)off + 256, V(0));
-    P.slots.assign((size_t)soff + 256, 0);
+    par_assign(P.vals, (size_t)off + 256, V(0)); // zeros: the padding of the packets
+    par_assign(P.slots, (size_t)soff + 256, (uint16_t)0);
     P.cvals.assign((size_t)coo + 256, V(0));
     P.crows.assign((size_t)coo + 256, 0);
     P.ccols.assign((size_t)coo + 256, 0);
@@ -898,7 +937,7 @@ template <typename V> struct Builder {
     P.frows.assign((size_t)P.far_len + 256, 0);
     P.fcols.assign((size_t)P.far_len + 256, 0);
     if (opt.keep_value_map) {
-      P.val_map.assign((size_t)off + 256, -1);
+      par_assign(P.val_map, (size_t)off + 256, (int32_t)-1);
       P.cval_map.assign((size_t)coo + 256, -1);
       P.fval_map.assign((size_t)P.far_len + 256, -1);
       P.diag_map.assign((size_t)nvr + 1, -1);
@@ -1259,17 +1298,21 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 template <typename V>
 void cluster_rows_part(const int *rowptr, const int *colind, int pb, int pe, int block_re,
                        int ngroups, const double *share, std::vector<int32_t> &perm,
-                       std::vector<int32_t> &chunk, bool mirror) {
+                       std::vector<int32_t> &chunk, bool mirror, int64_t total_known = -1) {
   const int rows = pe - pb;
   const int64_t per_nz = (int64_t)sizeof(V) + 2, per_row = 4 + 5 * (int64_t)sizeof(V);
-  int64_t total = (int64_t)rows * per_row, inblock = 0;
-  for (int i = pb; i < pe; i++)
-    for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-      int c = colind[j];
-      if (c < pb || (mirror && c >= block_re)) total += per_nz;
-      else if (c < pe && c != i) inblock++;
-    }
-  total += inblock / 2 * per_nz;
+  int64_t total = total_known;
+  if (total < 0) { // (the caller of the parts has counted already)
+    int64_t left = 0, inblock = 0;
+#pragma omp parallel for schedule(static) reduction(+ : left, inblock) num_threads(host_threads()) if (!omp_in_parallel())
+    for (int i = pb; i < pe; i++)
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        int c = colind[j];
+        if (c < pb || (mirror && c >= block_re)) left++;
+        else if (c < pe && c != i) inblock++;
+      }
+    total = (int64_t)rows * per_row + (left + inblock / 2) * per_nz;
+  }
   perm.clear();
   perm.reserve(rows);
   chunk.assign(ngroups + 1, pe);
@@ -1340,6 +1383,10 @@ void cluster_rows_part(const int *rowptr, const int *colind, int pb, int pe, int
 // decides which end stores an entry, as it does across the tiles of the natural
 // order; inside a part nothing changes.  (A small block keeps the single sweep: that
 // is what numbers the hub rows of an arrow matrix early.)
+inline int kMaxParts() {
+  if (const char *e = getenv("CFS_CLUSTER_PARTS")) return std::max(1, atoi(e));
+  return 8;
+}
 template <typename V>
 void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, int ngroups,
                   const std::vector<double> &share_in, std::vector<int32_t> &perm,
@@ -1350,7 +1397,7 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
   if ((int)share_in.size() == ngroups) share = share_in;
   int parts = 1;
   if (rows >= 200000 && ngroups >= 64)
-    while (parts * 2 <= std::min(host_threads(), 8) && ngroups % (parts * 2) == 0 &&
+    while (parts * 2 <= std::min(host_threads(), kMaxParts()) && ngroups % (parts * 2) == 0 &&
            ngroups / (parts * 2) >= 16)
       parts *= 2;
   if (parts == 1) {
@@ -1382,17 +1429,31 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
     int r = (int)(std::lower_bound(cost.begin(), cost.end(), target) - cost.begin());
     pb[p] = std::max(pb[p - 1], rb + std::min(r, rows));
   }
+  std::vector<int64_t> part_left(parts, 0), part_in(parts, 0);
   { // parts only pay when the given order has locality: most neighbours of a row must
     // lie in its own part (a randomly numbered mesh has them everywhere -- one sweep then)
+    // (the same pass counts what every part's sweep needs: its total cost)
     int64_t inpart = 0, inblock = 0;
-#pragma omp parallel for schedule(static) reduction(+ : inpart, inblock) num_threads(host_threads())
-    for (int i = rb; i < re; i++) {
-      const int p = (int)(std::upper_bound(pb.begin(), pb.end(), i) - pb.begin()) - 1;
-      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-        const int c = colind[j];
-        if (c < rb || c >= re || c == i) continue;
-        inblock++;
-        if (c >= pb[p] && c < pb[p + 1]) inpart++;
+#pragma omp parallel num_threads(host_threads())
+    {
+      std::vector<int64_t> l_left(parts, 0), l_in(parts, 0);
+#pragma omp for schedule(static) reduction(+ : inpart, inblock) nowait
+      for (int i = rb; i < re; i++) {
+        const int p = (int)(std::upper_bound(pb.begin(), pb.end(), i) - pb.begin()) - 1;
+        for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+          const int c = colind[j];
+          if (c < pb[p] || (mirror && c >= re)) l_left[p]++;
+          else if (c < pb[p + 1] && c != i) l_in[p]++;
+          if (c < rb || c >= re || c == i) continue;
+          inblock++;
+          if (c >= pb[p] && c < pb[p + 1]) inpart++;
+        }
+      }
+      for (int p = 0; p < parts; p++) {
+#pragma omp atomic
+        part_left[p] += l_left[p];
+#pragma omp atomic
+        part_in[p] += l_in[p];
       }
     }
     if (inpart * 10 < inblock * 8) {
@@ -1404,7 +1465,8 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
 #pragma omp parallel for schedule(static, 1) num_threads(parts)
   for (int p = 0; p < parts; p++)
     cluster_rows_part<V>(rowptr, colind, pb[p], pb[p + 1], re, gpp, share.data() + p * gpp,
-                         pperm[p], pchunk[p], mirror);
+                         pperm[p], pchunk[p], mirror,
+                         (int64_t)(pb[p + 1] - pb[p]) * per_row + (part_left[p] + part_in[p] / 2) * per_nz);
   perm.clear();
   perm.reserve(rows);
   chunk.assign(ngroups + 1, re);
@@ -1422,9 +1484,21 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
 template <typename V> struct ScheduleSpace {
   bool valid = false;
   int rb = 0, re = 0, nchunks = 0;
-  std::vector<int32_t> perm, chunk, brp, bci;
-  std::vector<V> bva;
-  std::vector<int32_t> bsr; // keep_value_map: entry -> position in the caller's values[]
+  std::vector<int32_t> perm, chunk, brp;
+  BigVec<int32_t> bci;
+  BigVec<V> bva;
+  BigVec<int32_t> bsr; // keep_value_map: entry -> position in the caller's values[]
+  ScheduleSpace() = default;
+  ScheduleSpace(const ScheduleSpace &) = delete;
+  ScheduleSpace &operator=(const ScheduleSpace &) = delete;
+  ~ScheduleSpace() { drop(); }
+  void drop() {
+    valid = false;
+    release_async(bci);
+    release_async(bva);
+    release_async(bsr);
+    std::vector<int32_t>().swap(brp);
+  }
 };
 
 // Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the full
@@ -1489,11 +1563,13 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   pt.lap("cluster_rows");
   std::vector<int32_t> inv(rows);
   for (int p = 0; p < rows; p++) inv[perm[p] - rb] = rb + p;
-  // the lower triangle + diagonal in schedule space.  Row p of it holds the
-  // neighbours of its original row that are numbered before p (or lie left of
-  // the block); every VALUE is taken from the original LOWER triangle (the
-  // entry (max(i,c), min(i,c))), which is all the reference's SSS path reads.
-  // Rows are independent: counted, filled and sorted in parallel.
+  // the lower triangle + diagonal in schedule space.  Every stored LOWER entry
+  // (i, c), c <= i, of the block -- all the reference's SSS path reads -- lands on
+  // exactly one schedule row: the later one of the two rows it couples, with the
+  // earlier one as its column (off-block columns keep their original numbering and
+  // stay with row i).  A scatter, not a gather: no entry has to look for its mirror
+  // image.  A mirrored shard also keeps the UPPER off-block entries (i, c >= re) of
+  // its rows, one-sided, valued from the lower entry (c, i) of the rank above.
   auto lower_value_pos = [&](int hi, int lo) -> int { // position of (hi, lo), hi > lo
     int b = rowptr[hi], e = rowptr[hi + 1];
     int l = b, r = e;
@@ -1509,28 +1585,83 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   };
   std::vector<int32_t> &brp = sp.brp;
   brp.assign((size_t)n + 2, 0);
+  {
+    int32_t *cnt = brp.data() + 1; // cnt[p]: entries of schedule row p
 #pragma omp parallel for schedule(static) num_threads(host_threads())
-  for (int p = rb; p < re; p++) {
-    const int i = perm[p - rb];
-    int cnt = 0;
-    for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-      const int c = colind[j];
-      if (c == i || c < rb || (mirror && c >= re)) cnt++;
-      else if (c < re && inv[c - rb] < p) cnt++;
+    for (int i = rb; i < re; i++) {
+      const int p = inv[i - rb];
+      int own = 0;
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        const int c = colind[j];
+        if (c > i) {
+          own += mirror && c >= re;
+        } else if (c == i || c < rb) {
+          own++;
+        } else {
+          const int pc = inv[c - rb];
+          if (pc < p) own++;
+          else __atomic_fetch_add(&cnt[pc], 1, __ATOMIC_RELAXED);
+        }
+      }
+      __atomic_fetch_add(&cnt[p], own, __ATOMIC_RELAXED);
     }
-    brp[p + 1] = cnt;
   }
   for (int p = rb; p < re; p++) brp[p + 1] += brp[p]; // rows < rb are empty
   for (int p = re + 1; p <= n + 1; p++) brp[p] = brp[re]; // rows >= re too (brp[n] = nnz)
   const int64_t bnnz = brp[re];
-  std::vector<int32_t> &bci = sp.bci;
-  std::vector<V> &bva = sp.bva;
-  bci.assign((size_t)bnnz + 1, 0);
-  bva.assign((size_t)bnnz + 1, V(0));
-  std::vector<int32_t> &bsr = sp.bsr;
+  // (not filled: the scatter below writes every entry, its threads touch the pages)
+  BigVec<int32_t> &bci = sp.bci;
+  BigVec<V> &bva = sp.bva;
+  bci.clear();
+  bva.clear();
+  bci.resize((size_t)bnnz + 1);
+  bva.resize((size_t)bnnz + 1);
+  bci[bnnz] = 0;
+  bva[bnnz] = V(0);
+  BigVec<int32_t> &bsr = sp.bsr;
   bsr.clear();
-  if (opt.keep_value_map) bsr.assign((size_t)bnnz + 1, -1);
+  if (opt.keep_value_map) {
+    bsr.resize((size_t)bnnz + 1);
+    bsr[bnnz] = -1;
+  }
   bool asym = false;
+  {
+    std::vector<int32_t> cur(brp.begin() + rb, brp.begin() + re); // fill cursor per schedule row
+    const bool maps = !bsr.empty();
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+    for (int i = rb; i < re; i++) {
+      const int p = inv[i - rb];
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
+        const int c = colind[j];
+        int row = p, col, src = j;
+        if (c > i) {
+          if (!(mirror && c >= re)) continue;
+          col = c;
+          src = lower_value_pos(c, i);
+          if (src < 0) {
+#pragma omp atomic write
+            asym = true; // no lower image: the mirror check refuses such blocks anyway
+            src = j;
+          }
+        } else if (c == i) {
+          col = p;
+        } else if (c < rb) {
+          col = c;
+        } else {
+          const int pc = inv[c - rb];
+          if (pc < p) col = pc;
+          else row = pc, col = p;
+        }
+        const int q = __atomic_fetch_add(&cur[row - rb], 1, __ATOMIC_RELAXED);
+        bci[q] = col;
+        bva[q] = values[src];
+        if (maps) bsr[q] = src;
+      }
+    }
+  }
+  // the entries of a row arrived in any order: sort them by column.  Duplicate
+  // entries (the reader keeps them) would make that order -- and with it the
+  // schedule -- depend on the race above: such matrices keep their natural order.
 #pragma omp parallel num_threads(host_threads())
   {
     struct Ent {
@@ -1539,55 +1670,32 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
       int32_t src;
     };
     std::vector<Ent> tmp;
-#pragma omp for schedule(dynamic, 256)
+    const bool maps = !bsr.empty();
+    bool dup = false;
+#pragma omp for schedule(dynamic, 1024) nowait
     for (int p = rb; p < re; p++) {
-      const int i = perm[p - rb];
-      tmp.clear();
-      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
-        const int c = colind[j];
-        int col;
-        if (c == i) col = p;
-        else if (c < rb || (mirror && c >= re)) col = c; // off-block: original numbering
-        else if (c < re && inv[c - rb] < p) col = inv[c - rb];
-        else continue;
-        int src = j; // (i, c) with c <= i is a lower entry itself
-        if (c > i) {
-          src = lower_value_pos(c, i);
-          if (src < 0) {
-#pragma omp atomic write
-            asym = true; // structurally unsymmetric input: keep the natural order
-            src = j;
-          }
+      const int b = brp[p], e = brp[p + 1];
+      bool sorted = true;
+      for (int q = b + 1; q < e; q++)
+        if (bci[q] <= bci[q - 1]) {
+          sorted = false;
+          break;
         }
-        tmp.push_back(Ent{col, values[src], src});
-      }
-      std::stable_sort(tmp.begin(), tmp.end(),
-                       [](const Ent &x, const Ent &y) { return x.first < y.first; });
-      int q = brp[p];
-      for (size_t k = 0; k < tmp.size(); k++) {
-        // duplicate entries (the reader keeps them) cannot be paired with their
-        // mirror images one to one: such matrices keep their natural order
-        if (k > 0 && tmp[k].first == tmp[k - 1].first) {
-#pragma omp atomic write
-          asym = true;
-        }
-        bci[q] = tmp[k].first;
-        bva[q] = tmp[k].second;
-        if (!bsr.empty()) bsr[q] = tmp[k].src;
-        q++;
+      if (sorted) continue;
+      tmp.resize((size_t)(e - b));
+      for (int q = b; q < e; q++) tmp[q - b] = Ent{bci[q], bva[q], maps ? bsr[q] : 0};
+      std::sort(tmp.begin(), tmp.end(), [](const Ent &x, const Ent &y) { return x.first < y.first; });
+      for (int q = b; q < e; q++) {
+        if (q > b && tmp[q - b].first == tmp[q - b - 1].first) dup = true;
+        bci[q] = tmp[q - b].first;
+        bva[q] = tmp[q - b].second;
+        if (maps) bsr[q] = tmp[q - b].src;
       }
     }
-  }
-  if (!asym) {
-    // every stored entry of the block must have landed on exactly one schedule row:
-    // a lower entry whose upper image is missing (structurally unsymmetric input)
-    // is lost when its column comes later in the schedule than its row
-    int64_t want = 0;
-#pragma omp parallel for schedule(static) reduction(+ : want) num_threads(host_threads())
-    for (int i = rb; i < re; i++)
-      for (int j = rowptr[i]; j < rowptr[i + 1]; j++)
-        if (colind[j] <= i || (mirror && colind[j] >= re)) want++;
-    if (want != bnnz) asym = true;
+    if (dup) {
+#pragma omp atomic write
+      asym = true;
+    }
   }
   if (asym)
     return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt,
@@ -1632,9 +1740,9 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
     sp.nchunks = nchunks;
     return true;
   }
-  std::vector<int32_t>().swap(bci);
-  std::vector<V>().swap(bva);
-  std::vector<int32_t>().swap(bsr);
+  release_async(bci);
+  release_async(bva);
+  release_async(bsr);
   return build_plan_core<V>(n, rowptr, colind, values, nranks, rank, row_splits_in, opt, nullptr,
                             nullptr, P);
 }
