@@ -54,7 +54,7 @@ void cfs_rt::parallel_copy(void *dst, const void *src, size_t bytes) {
 template <typename V> struct SymDev {
   const Tile *tiles;
   const Tile *gfirst;
-  const int32_t *group_ptr;
+  const int2 *group_range; // per launch slot: [first, last) tile
   const int32_t *slot_col; // original column of every slot of every tile
   const uint32_t *rowinfo;
   const V *diag;
@@ -250,7 +250,7 @@ __device__ __forceinline__ void coo_update(const V *xl, const YWin<DET> &yl, V a
 template <typename V, int BLOCK, int MODE, bool NT, bool OFFB, int U, bool DET = false>
 __global__ void __launch_bounds__(BLOCK, 4)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const Tile *__restrict__ a_gfirst,
-                        const int32_t *__restrict__ a_group_ptr,
+                        const int2 *__restrict__ a_group_range,
                         const int32_t *__restrict__ a_slot_col,
                         const uint32_t *__restrict__ a_rowinfo, const V *__restrict__ a_diag,
                         const uint4 *__restrict__ a_slice_meta,
@@ -268,7 +268,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
   struct {
     const Tile *__restrict__ tiles;
     const Tile *__restrict__ gfirst;
-    const int32_t *__restrict__ group_ptr;
+    const int2 *__restrict__ group_range;
     const int32_t *__restrict__ slot_col;
     const uint32_t *__restrict__ rowinfo;
     const V *__restrict__ diag;
@@ -284,7 +284,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
     const int32_t *__restrict__ fcols;
     V *__restrict__ strip;
     int row_begin, lds_slots;
-  } d = {a_tiles, a_gfirst, a_group_ptr, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_leadlane, a_vals,
+  } d = {a_tiles, a_gfirst, a_group_range, a_slot_col, a_rowinfo, a_diag, a_slice_meta, a_leadlane, a_vals,
          a_slots, a_cvals, a_crows, a_ccols, a_fvals, a_frows, a_fcols, a_strip, a_row_begin, a_lds_slots};
   // slice ticket counter of the current tile (16 B so the dynamic region below
   // stays 16-byte aligned)
@@ -310,8 +310,11 @@ __global__ void __launch_bounds__(BLOCK, 4)
   // contiguous run of groups so neighbouring tiles share halo lines in one L2.
   // Placement only affects speed, never correctness.
   const int nper = gridDim.x >> 3;
+  // (g is a launch SLOT: which group of the plan runs in it is the host's choice,
+  // SymPlan::launch_order -- gfirst / group_range are stored in slot order)
   const int g = (blockIdx.x & 7) * nper + (blockIdx.x >> 3);
-  const int t0 = d.group_ptr[g], t1 = d.group_ptr[g + 1];
+  const int2 trange = d.group_range[g];
+  const int t0 = trange.x, t1 = trange.y;
   // developer timeline (cfs_hip_sym_debug_timeline): 100 MHz wall clock stamps of
   // this workgroup's phases; dbg is NULL in every product launch
   if (dbg && tid == 0) dbg[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
@@ -896,8 +899,18 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
 #define UP(buf, vec)                                                          \
   if ((rc = buf.upload(vec.data(), vec.size() * sizeof(vec[0])))) return rc;
     UP(tiles, P.tiles)
-    UP(gfirst, P.group_first)
-    UP(group_ptr, P.group_ptr)
+    { // per launch slot: first tile + tile range of the group that runs there
+      const int G = (int)P.group_first.size();
+      std::vector<Tile> gf(G);
+      std::vector<int2> gr(G);
+      for (int sl = 0; sl < G; sl++) {
+        const int g = (int)P.launch_order.size() == G ? P.launch_order[sl] : sl;
+        gf[sl] = P.group_first[g];
+        gr[sl] = make_int2(P.group_ptr[g], P.group_ptr[g + 1]);
+      }
+      UP(gfirst, gf)
+      UP(group_ptr, gr)
+    }
     UP(slot_col, P.slot_col)
     UP(rowinfo, P.rowinfo)
     UP(diag, P.diag)
@@ -946,7 +959,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     nsend = (int)P.send_row.size();
     dev.tiles = (const Tile *)tiles.p;
     dev.gfirst = (const Tile *)gfirst.p;
-    dev.group_ptr = (const int32_t *)group_ptr.p;
+    dev.group_range = (const int2 *)group_ptr.p;
     dev.slot_col = (const int32_t *)slot_col.p;
     dev.rowinfo = (const uint32_t *)rowinfo.p;
     dev.diag = (const V *)diag.p;
@@ -1025,7 +1038,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     const void *k = tile_kernel();
     int rc = raise_lds_limit(k, device);
     if (rc) return rc;
-    void *args[] = {(void *)&dev.tiles, (void *)&dev.gfirst, (void *)&dev.group_ptr,
+    void *args[] = {(void *)&dev.tiles, (void *)&dev.gfirst, (void *)&dev.group_range,
                     (void *)&dev.slot_col, (void *)&dev.rowinfo, (void *)&dev.diag,
                     (void *)&dev.slice_meta, (void *)&dev.leadlane, (void *)&dev.vals,
                     (void *)&dev.slots,
@@ -1145,8 +1158,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     if (cap < P.ngroups * CFS_HIP_GROUP_FEATURES)
       return set_err(CFS_HIP_ERR_ARG, "buffer too small");
     const int T = (int)P.tiles.size();
-    for (int g = 0; g < P.ngroups; g++) {
-      long long *o = out + (size_t)g * CFS_HIP_GROUP_FEATURES;
+    for (int sl = 0; sl < P.ngroups; sl++) { // in launch-slot order
+      const int g = (int)P.launch_order.size() == P.ngroups ? P.launch_order[sl] : sl;
+      long long *o = out + (size_t)sl * CFS_HIP_GROUP_FEATURES;
       for (int k = 0; k < CFS_HIP_GROUP_FEATURES; k++) o[k] = 0;
       for (int ti = P.group_ptr[g]; ti < P.group_ptr[g + 1]; ti++) {
         const Tile &t = P.tiles[ti];
@@ -1336,6 +1350,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
   if (const char *e = getenv("CFS_HIP_FAR_USES"))
     if (atoi(e) > 0) r.far_uses = atoi(e);
   if (const char *e = getenv("CFS_HIP_HYB")) r.hyb = atoi(e) != 0;
+  if (const char *e = getenv("CFS_HIP_COST_MODEL")) r.cost_model = atoi(e) != 0;
   if (const char *e = getenv("CFS_HIP_DETERMINISTIC")) r.deterministic = atoi(e) != 0;
   if (r.deterministic) { // one kernel shape, no far entries (see YWin)
     r.hyb = false;
@@ -1350,6 +1365,13 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     const char *e = getenv("CFS_HIP_MAX_SLOTS");
     if (e && atoi(e) > 0) r.max_slots = atoi(e);
   }
+  // developer knob (tools/calib_probe.py): relative cost share of every persistent group
+  if (const char *e = getenv("CFS_HIP_GROUP_SHARE_FILE"))
+    if (FILE *f = fopen(e, "r")) {
+      double v;
+      while (fscanf(f, "%lf", &v) == 1) r.group_share.push_back(v);
+      fclose(f);
+    }
   return r;
 }
 

@@ -69,6 +69,7 @@ struct Options {
   // relative work share of every persistent group (size = number of groups,
   // any positive scale); empty = equal shares.
   std::vector<double> group_share;
+  bool cost_model = true; // tiles / halo / dispatch wave in the cost of a group (ClusterCost)
   // Shards (nranks > 1): off-block entries are stored by BOTH ranks they touch and
   // processed one-sided (row side only): a row of the block also carries its
   // entries a_ri of rows r owned by higher ranks, and its entries left of the
@@ -213,6 +214,9 @@ template <typename V> struct SymPlan {
   std::vector<int32_t> group_ptr;   // [ngroups+1] tiles of persistent group g
   std::vector<Tile> group_first;    // [ngroups] copy of each group's first tile: one
                                     // dependent load less at kernel start
+  std::vector<int32_t> launch_order; // [ngroups] launch slot -> group (workgroup b runs slot
+                                    // (b % 8) * (ngroups / 8) + b / 8); a permutation inside
+                                    // every XCD's run of ngroups / 8 slots
   std::vector<int32_t> halo_col;    // [H] column of every halo slot (schedule space)
   std::vector<int32_t> slot_col;    // [sum nslots + 1] ORIGINAL column of every slot
   std::vector<int32_t> perm;        // [rows] schedule row -> original row (empty = identity)
@@ -311,8 +315,31 @@ inline void balanced_splits(int n, const int *rowptr, const int *colind,
 
 // The launch layout: `ngroups` cost-balanced chunks of rows, one per persistent
 // workgroup -- as many as are co-resident, fewer for a small matrix.
+// What a group costs beyond the bytes it streams, in byte-equivalents of one
+// workgroup's share of the HBM rate.  Fitted to the per-workgroup timeline of the tile
+// kernel on the Flan stand-in (tools/calib_probe.py): a workgroup's end time grows by
+// 4-5 us per tile beyond its first (window epilogue + prologue, the split's own halo)
+// and by 1 ns per halo slot.  The 10-20 two-tile groups of a launch -- the ragged last
+// clusters of every clustering sweep, 2.4x the median halo -- used to end 10 us after
+// the rest and set its length.  The model is used twice: clusters grow to equal MODEL
+// cost (cluster_rows_part), and the launch order puts the expensive groups into the
+// first dispatch wave (Builder::finish).  Coefficients between 3 and 8 us / 0.5 and
+// 1.5 ns measure the same (+4 % on the headline); larger ones lose again.
+constexpr double kHbmRate = 6.2e12;       // B/s the tile kernel sustains (section 4 of DESIGN.md)
+inline double env_or(const char *name, double dflt) {
+  const char *e = getenv(name);
+  return e ? atof(e) : dflt;
+}
+static const double kTileSeconds = 1e-6 * env_or("CFS_HIP_TILE_US", 5.5);   // per tile beyond the first of a group
+static const double kHaloSeconds = 1e-9 * env_or("CFS_HIP_HALO_NS", 1.0);   // per halo slot
+struct ClusterCost {
+  int max_slots = 0;   // LDS window of a tile (0: byte cost only)
+  double per_halo = 0; // byte-equivalents per halo slot
+  double per_tile = 0; // byte-equivalents per tile beyond the first
+};
 struct ChunkLayout {
-  int block = 0, max_slots = 0, ngroups = 0;
+  int block = 0, max_slots = 0, ngroups = 0, wg_per_cu = 1;
+  bool full_grid = false; // as many groups as workgroups are co-resident
   int nchunks() const { return ngroups; }
   // relative cost share of every chunk, in chunk order
   std::vector<double> shares(const Options &opt) const {
@@ -320,6 +347,14 @@ struct ChunkLayout {
     if ((int)opt.group_share.size() == ngroups)
       for (int g = 0; g < ngroups; g++) s[g] = std::max(opt.group_share[g], 1e-9);
     return s;
+  }
+  ClusterCost cluster_cost(const Options &opt) const {
+    ClusterCost c;
+    if (!opt.cost_model) return c;
+    c.max_slots = max_slots;
+    c.per_halo = kHaloSeconds * kHbmRate / std::max(ngroups, 1);
+    c.per_tile = kTileSeconds * kHbmRate / std::max(ngroups, 1);
+    return c;
   }
 };
 template <typename V> inline ChunkLayout chunk_layout(int rows, const Options &opt) {
@@ -344,9 +379,11 @@ template <typename V> inline ChunkLayout chunk_layout(int rows, const Options &o
   const int ncu = opt.num_cus > 0 ? opt.num_cus : 256;
   int ngroups = (ncu * wg_per_cu + 7) / 8 * 8;
   const int by_rows = ((rows + min_rows_per_group() - 1) / min_rows_per_group() + 7) / 8 * 8;
+  L.full_grid = ngroups <= by_rows;
   if (ngroups > by_rows) ngroups = by_rows;
   if (ngroups < 8) ngroups = 8;
   L.ngroups = ngroups;
+  L.wg_per_cu = wg_per_cu;
   return L;
 }
 
@@ -1219,6 +1256,36 @@ template <typename V> struct Builder {
     P.fold_dst.resize(P.fold_row.size());
     for (size_t i = 0; i < P.fold_row.size(); i++) P.fold_dst[i] = orig(P.fold_row[i] + rb) - rb;
     if (perm_in) P.perm = *perm_in;
+    // Which workgroup runs which group.  With two workgroups per CU the dispatcher
+    // places workgroups 0 .. G/2-1 first (one per CU) and G/2 .. G-1 as the second
+    // workgroup of the same CUs: those start 2 us later and -- the older workgroup of a
+    // CU wins its arbitration -- end 5 us later (tools/calib_probe.py).  The expensive
+    // groups of an XCD's run (several tiles, ragged clusters with much halo: the last
+    // clusters of every clustering sweep) therefore go FIRST, and the second workgroup
+    // of a CU is the cheapest partner for its first: longest-processing-time pairing
+    // on the model cost of a group.  Same XCD, same L2 as before.
+    P.launch_order.resize(nc);
+    for (int g = 0; g < nc; g++) P.launch_order[g] = g;
+    if (opt.cost_model && L.full_grid && L.wg_per_cu == 2 && nc % 16 == 0 && env_or("CFS_HIP_LAUNCH_ORDER", 1) != 0) {
+      const ClusterCost cm = L.cluster_cost(opt);
+      std::vector<double> gc(nc, 0.0);
+      for (int g = 0; g < nc; g++) {
+        const int t0 = P.group_ptr[g], t1 = P.group_ptr[g + 1];
+        for (int ti = t0; ti < t1; ti++) gc[g] += (double)(P.tiles[ti].nslots - P.tiles[ti].nown) * cm.per_halo;
+        gc[g] += (double)std::max(0, t1 - t0 - 1) * cm.per_tile;
+        if (t1 > t0) gc[g] += (double)(cost[P.tiles[t1 - 1].row0 + P.tiles[t1 - 1].nown - rb] - cost[P.tiles[t0].row0 - rb]);
+      }
+      const int nper = nc / 8, h = nper / 2;
+      std::vector<int32_t> idx(nper);
+      for (int x = 0; x < 8; x++) {
+        for (int k = 0; k < nper; k++) idx[k] = x * nper + k;
+        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return gc[a] > gc[b]; });
+        for (int j = 0; j < h; j++) {
+          P.launch_order[x * nper + j] = idx[j];                // first wave: heaviest first
+          P.launch_order[x * nper + h + j] = idx[nper - 1 - j]; // its CU partner: lightest
+        }
+      }
+    }
   }
 
   // the whole build; cut_only: the caller only wants to compare halo sizes of two row orders
@@ -1298,7 +1365,8 @@ bool build_plan_core(int n, const int *rowptr, const int *colind, const V *value
 template <typename V>
 void cluster_rows_part(const int *rowptr, const int *colind, int pb, int pe, int block_re,
                        int ngroups, const double *share, std::vector<int32_t> &perm,
-                       std::vector<int32_t> &chunk, bool mirror, int64_t total_known = -1) {
+                       std::vector<int32_t> &chunk, bool mirror, int64_t total_known = -1,
+                       const ClusterCost &cm = ClusterCost(), int ncols = 0) {
   const int rows = pe - pb;
   const int64_t per_nz = (int64_t)sizeof(V) + 2, per_row = 4 + 5 * (int64_t)sizeof(V);
   int64_t total = total_known;
@@ -1321,17 +1389,33 @@ void cluster_rows_part(const int *rowptr, const int *colind, int pb, int pe, int
   std::vector<int32_t> bfs, seeds;
   size_t seed_head = 0;
   int next_free = 0;
-  int64_t cum = 0;
   std::vector<double> cumshare(ngroups + 1, 0.0);
   for (int g = 0; g < ngroups; g++) cumshare[g + 1] = cumshare[g] + std::max(share[g], 1e-9);
+  // the cost model (ClusterCost): a cluster also pays for its halo slots -- distinct
+  // columns outside it that its rows store: rows of earlier clusters, columns left of
+  // the part -- and for every LDS window beyond its first.  What that adds up to is
+  // only known at the end, so every cluster's target is its share of what is LEFT:
+  // the bytes not yet assigned plus the extras the remaining clusters are expected
+  // to pay (at the rate seen so far).
+  const bool model = cm.max_slots > 0 && ncols > 0;
+  struct Zeroed { // lazily zeroed pages: only the marks that are touched cost memory
+    int32_t *p;
+    explicit Zeroed(size_t k) : p(k ? (int32_t *)calloc(k, sizeof(int32_t)) : nullptr) {}
+    ~Zeroed() { free(p); }
+  } inmark(model ? (size_t)rows : 0), outmark(model ? (size_t)ncols : 0);
+  int64_t cum_bytes = 0;
+  double cum_extra = 0.0;
   for (int g = 0; g < ngroups; g++) {
-    const int64_t target = (g == ngroups - 1)
-                               ? total + 1
-                               : (int64_t)((double)total * (cumshare[g + 1] / cumshare[ngroups]));
+    const double s_rem = cumshare[ngroups] - cumshare[g];
+    const double extra_rate = g > 0 ? cum_extra / cumshare[g] : 0.0;
+    const double target = ((double)(total - cum_bytes) + extra_rate * s_rem) * (cumshare[g + 1] - cumshare[g]) / s_rem;
+    const bool last = g == ngroups - 1;
     const size_t first = perm.size();
     bfs.clear();
     size_t head = 0;
-    while ((int)perm.size() < rows && (cum < target || g == ngroups - 1)) {
+    int64_t bytes_g = 0, halo_g = 0, rows_g = 0;
+    double extra_g = 0.0;
+    while ((int)perm.size() < rows && (last || (double)bytes_g + extra_g < target)) {
       if (head == bfs.size()) { // need a seed: oldest frontier row, else next free row
         int sd = -1;
         while (seed_head < seeds.size()) {
@@ -1354,11 +1438,21 @@ void cluster_rows_part(const int *rowptr, const int *colind, int pb, int pe, int
       const int i = pb + v;
       for (int j = rowptr[i]; j < rowptr[i + 1]; j++) {
         const int c = colind[j];
-        if (c < pb || (mirror && c >= block_re)) low++;
-        else if (c < pe && c != i) {
+        if (c < pb || (mirror && c >= block_re)) {
+          low++;
+          if (model && (unsigned)c < (unsigned)ncols && outmark.p[c] != g + 1) {
+            outmark.p[c] = g + 1;
+            halo_g++;
+          }
+        } else if (c < pe && c != i) {
           const int u = c - pb;
-          if (state[u] >= 0) low++;
-          else if (state[u] != -2 - g) {
+          if (state[u] >= 0) {
+            low++;
+            if (model && state[u] != g && inmark.p[u] != g + 1) {
+              inmark.p[u] = g + 1;
+              halo_g++;
+            }
+          } else if (state[u] != -2 - g) {
             state[u] = -2 - g;
             bfs.push_back(u);
           }
@@ -1366,8 +1460,14 @@ void cluster_rows_part(const int *rowptr, const int *colind, int pb, int pe, int
       }
       state[v] = g;
       perm.push_back(i);
-      cum += (int64_t)low * per_nz + per_row;
+      rows_g++;
+      bytes_g += (int64_t)low * per_nz + per_row;
+      if (model)
+        extra_g = (double)halo_g * cm.per_halo +
+                  (double)((rows_g + halo_g - 1) / cm.max_slots) * cm.per_tile;
     }
+    cum_bytes += bytes_g;
+    cum_extra += extra_g;
     for (size_t k = head; k < bfs.size(); k++) { // unfinished frontier -> future seeds
       state[bfs[k]] = -1;
       seeds.push_back(bfs[k]);
@@ -1390,8 +1490,8 @@ inline int kMaxParts() {
 template <typename V>
 void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, int ngroups,
                   const std::vector<double> &share_in, std::vector<int32_t> &perm,
-                  std::vector<int32_t> &chunk, bool mirror = false) {
-  (void)n;
+                  std::vector<int32_t> &chunk, bool mirror = false,
+                  const ClusterCost &cm = ClusterCost()) {
   const int rows = re - rb;
   std::vector<double> share(ngroups, 1.0);
   if ((int)share_in.size() == ngroups) share = share_in;
@@ -1401,7 +1501,7 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
            ngroups / (parts * 2) >= 16)
       parts *= 2;
   if (parts == 1) {
-    cluster_rows_part<V>(rowptr, colind, rb, re, re, ngroups, share.data(), perm, chunk, mirror);
+    cluster_rows_part<V>(rowptr, colind, rb, re, re, ngroups, share.data(), perm, chunk, mirror, -1, cm, n);
     return;
   }
   // part boundaries: the cost every order agrees on (an entry across a boundary is
@@ -1457,7 +1557,7 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
       }
     }
     if (inpart * 10 < inblock * 8) {
-      cluster_rows_part<V>(rowptr, colind, rb, re, re, ngroups, share.data(), perm, chunk, mirror);
+      cluster_rows_part<V>(rowptr, colind, rb, re, re, ngroups, share.data(), perm, chunk, mirror, -1, cm, n);
       return;
     }
   }
@@ -1466,7 +1566,8 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
   for (int p = 0; p < parts; p++)
     cluster_rows_part<V>(rowptr, colind, pb[p], pb[p + 1], re, gpp, share.data() + p * gpp,
                          pperm[p], pchunk[p], mirror,
-                         (int64_t)(pb[p + 1] - pb[p]) * per_row + (part_left[p] + part_in[p] / 2) * per_nz);
+                         (int64_t)(pb[p + 1] - pb[p]) * per_row + (part_left[p] + part_in[p] / 2) * per_nz,
+                         cm, n);
   perm.clear();
   perm.reserve(rows);
   chunk.assign(ngroups + 1, re);
@@ -1559,7 +1660,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   }
   sp.valid = false;
   std::vector<int32_t> &perm = sp.perm, &chunk = sp.chunk;
-  cluster_rows<V>(n, rowptr, colind, rb, re, nchunks, L.shares(opt), perm, chunk, mirror);
+  cluster_rows<V>(n, rowptr, colind, rb, re, nchunks, L.shares(opt), perm, chunk, mirror,
+                  L.cluster_cost(opt));
   pt.lap("cluster_rows");
   std::vector<int32_t> inv(rows);
   for (int p = 0; p < rows; p++) inv[perm[p] - rb] = rb + p;

@@ -286,8 +286,8 @@ int cfs_hip_sym_debug_timeline(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
                                unsigned long long *stamps, int capacity_words,
                                int *ngroups);
 
-/* developer diagnostic: what every persistent group (in group order; block b runs
- * group (b % 8) * (ngroups / 8) + b / 8) has to do, CFS_HIP_GROUP_FEATURES words
+/* developer diagnostic: what the group in every launch slot (block b runs slot
+ * (b % 8) * (ngroups / 8) + b / 8) has to do, CFS_HIP_GROUP_FEATURES words
  * each: [0] tiles, [1] rows, [2] virtual rows, [3] slices, [4] packet rounds (sum
  * over slices of the longest lane's packets), [5] value-stream entries, [6] slot-
  * stream entries, [7] COO leftovers, [8] halo slots, [9] slots.  tools/ fit the
