@@ -2053,6 +2053,21 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
     if ((int)P.group_ptr.size() != P.ngroups + 1 || P.ngroups % 8) bad++;
     for (size_t g = 1; g < P.group_ptr.size(); g++)
       if (P.group_ptr[g] < P.group_ptr[g - 1]) bad++;
+    // every group runs in exactly one launch slot, inside its own XCD's run of slots
+    if ((int)P.launch_order.size() != P.ngroups) {
+      bad++;
+    } else {
+      std::vector<char> seen(P.ngroups, 0);
+      const int nper = std::max(1, P.ngroups / 8);
+      for (int sl = 0; sl < P.ngroups; sl++) {
+        const int g = P.launch_order[sl];
+        if (g < 0 || g >= P.ngroups || seen[g] || g / nper != sl / nper) {
+          bad++;
+          continue;
+        }
+        seen[g] = 1;
+      }
+    }
     int row = P.row_begin;
     for (const Tile &t : P.tiles) {
       if (t.row0 != row || t.nslots > P.max_slots || t.nslots > P.lds_slots) bad++;

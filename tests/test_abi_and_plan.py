@@ -73,6 +73,17 @@ def test_schedule_encodes_the_lower_triangle(name, scale, dtype):
 FLAG_HYB, FLAG_CLUSTER, FLAG_NO_REORDER, FLAG_EXCHANGE = 128, 16, 8, 64
 
 
+@pytest.mark.parametrize("flags", [FLAG_CLUSTER, FLAG_NO_REORDER])
+def test_full_grid_schedule(flags):
+    """enough rows for one group per resident workgroup (512): the clusters grow to equal
+    MODEL cost (tiles, halo slots) and the launch order is a permutation inside every
+    XCD's run of slots -- plan_check verifies both the decoded entries and that order"""
+    n, rp, ci, va, low = synth.generate("Flan_1565", 0.2)
+    rep = cfs.plan_check(n, rp, ci, va, options=cfs.make_options(flags=flags))
+    assert rep["mismatches"] == 0 and rep["decoded"] == low
+    assert rep["ngroups"] == 512
+
+
 @pytest.mark.parametrize("name,scale", CASES + [("Flan_1565", 0.2), ("ldoor", 0.3)])
 @pytest.mark.parametrize("flags", [FLAG_HYB, FLAG_HYB | FLAG_CLUSTER, FLAG_HYB | FLAG_NO_REORDER])
 def test_hyb_schedules_encode_the_lower_triangle(name, scale, flags):
