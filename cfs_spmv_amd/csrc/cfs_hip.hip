@@ -1481,7 +1481,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     return r2;
   };
   auto try_alternative = [&](cfs_plan::Options &po2, cfs_plan::ScheduleSpace<V> *sp,
-                             const char *what) -> int {
+                             const char *what, int forced = -1) -> int {
     if (!xb.p) {
       int r2;
       if ((r2 = xb.alloc((size_t)n * sizeof(V))) || (r2 = yb.alloc((size_t)m->rows() * sizeof(V))))
@@ -1509,7 +1509,8 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     // (CFS_HIP_KEEP_ALT=1: developer knob -- keep the alternative whatever the clock says,
     // so that each of the schedules tune() may end up with can be profiled on any box)
     const char *force = getenv("CFS_HIP_KEEP_ALT");
-    if (ok && (t_alt < 0.99f * t_def || (force && atoi(force) != 0))) {
+    if (force && atoi(force) != 0) forced = 1;
+    if (ok && forced != 0 && (t_alt < 0.99f * t_def || forced == 1)) {
       delete m;
       m = alt;
       po = po2;
@@ -1525,7 +1526,11 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     cfs_plan::Options po2 = po;
     po2.block_threads = 1024;
     po2.max_slots = 2 * cfs_plan::kDefaultSlots;
-    if ((rc = try_alternative(po2, &space, "window shape 512 x 2 per CU vs 1024 x 1"))) {
+    // (CFS_HIP_SHAPE=512|1024: developer knob -- the profiler passes of one evidence set
+    // must run the schedule its bench line ran, whatever the clock says under the profiler)
+    int forced = -1;
+    if (const char *e = getenv("CFS_HIP_SHAPE")) forced = atoi(e) == 1024 ? 1 : (atoi(e) == 512 ? 0 : -1);
+    if ((rc = try_alternative(po2, &space, "window shape 512 x 2 per CU vs 1024 x 1", forced))) {
       delete m;
       return rc;
     }

@@ -15,6 +15,9 @@ tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
 python3 bench.py "$@" > $out/bench.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
+# the profiler passes run the window shape tune() kept in the bench run above (the two
+# shapes are within a few per cent of each other; under the profiler the clock may say otherwise)
+export CFS_HIP_SHAPE=$(python3 -c "import json,sys; print(json.load(open('$out/bench.json'))['config']['block_threads'])")
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" > $out/bench_traced.json 2> $out/trace.err
 cp $out/trace/*/*_kernel_stats.csv $out/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/pmc_f.err
