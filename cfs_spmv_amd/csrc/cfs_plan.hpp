@@ -184,7 +184,11 @@ template <typename T> inline void release_async(BigVec<T> &v) {
   if (v.capacity() * sizeof(T) < ((size_t)64 << 20)) return release(v);
   auto *h = new BigVec<T>();
   h->swap(v);
-  std::thread([h] { delete h; }).detach();
+  try {
+    std::thread([h] { delete h; }).detach();
+  } catch (...) { // no thread to be had: free it here
+    delete h;
+  }
 }
 // v = n copies of val, pages first touched (and filled) by all host threads
 template <typename T> inline void par_assign(BigVec<T> &v, size_t n, T val) {
