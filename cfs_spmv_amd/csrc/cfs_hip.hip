@@ -216,6 +216,42 @@ __device__ __forceinline__ void consume_packet(const Pkt<V> &p, const V *xl, con
   lds_update<V, MODE, OFFB, DET>(xl, yl, p.v[2], p.c.z, xi, acc, ny);
   lds_update<V, MODE, OFFB, DET>(xl, yl, p.v[3], p.c.w, xi, acc, ny);
 }
+// The lanes of one mesh node read the same slots, i.e. their transposed updates of one
+// packet entry go to the SAME y-window word: one instruction, up to three lanes on one
+// address.  A follower that sits right behind a lane of its group hands its product to
+// that lane (two DPP row shifts, runs of at most three lanes; cfs_plan sets the flags)
+// and only the head of a run issues the atomic: fewer active lanes, no same-address
+// serialisation.  `give` = my products go to my left neighbour, `take` = I add my right
+// neighbour's.  Inactive lanes contribute 0 (a follower never has more packets than
+// the lane to its left: lanes are sorted by packet count).
+__device__ __forceinline__ double row_shl1(double v) { // lane l <- lane l + 1 (0 at the end of a row of 16)
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x101, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x101, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+template <typename V, bool OFFB, bool DET>
+__device__ __forceinline__ void entry_combined(const V *xl, const YWin<DET> &yw, V a, unsigned c, V xi,
+                                               V &acc, unsigned ny, bool act, bool give, bool take) {
+  double pr = 0.0;
+  if (act) {
+    acc = fma(a, xl[c], acc);
+    pr = (double)a * (double)xi;
+  }
+  // (the shifts run with every lane enabled: a DPP read of a disabled lane returns nothing)
+  const double t1 = row_shl1(pr);
+  const double s1 = pr + (take ? t1 : 0.0);
+  const double t2 = row_shl1(s1);
+  const double q = pr + (take ? t2 : 0.0);
+  if (act && !give && (!OFFB || c < ny)) yw.add(c, q);
+}
+template <typename V, bool OFFB, bool DET>
+__device__ __forceinline__ void consume_combined(const Pkt<V> &p, const V *xl, const YWin<DET> &yl, V xi,
+                                                 V &acc, unsigned ny, bool act, bool give, bool take) {
+  entry_combined<V, OFFB, DET>(xl, yl, p.v[0], p.c.x, xi, acc, ny, act, give, take);
+  entry_combined<V, OFFB, DET>(xl, yl, p.v[1], p.c.y, xi, acc, ny, act, give, take);
+  entry_combined<V, OFFB, DET>(xl, yl, p.v[2], p.c.z, xi, acc, ny, act, give, take);
+  entry_combined<V, OFFB, DET>(xl, yl, p.v[3], p.c.w, xi, acc, ny, act, give, take);
+}
 // one COO leftover a = A[row(r)][col(c)]: both sides through LDS atomics
 template <typename V, int MODE, bool OFFB, bool DET>
 __device__ __forceinline__ void coo_update(const V *xl, const YWin<DET> &yl, V a, unsigned r,
@@ -427,9 +463,9 @@ __global__ void __launch_bounds__(BLOCK, 4)
       info_c = p0 < nvr ? i0 : 0u;
       dg_c = p0 < nvr ? d0 : V(0);
       const unsigned long long lead0 = ((unsigned long long)meta_c.w << 32) | meta_c.z;
-      lr_c = leader_rank(lead0, L_c);
+      lr_c = leader_rank(lead0, L_c & 63) | (L_c & 0xc0); // bits 6 / 7: sibling chain (entry_combined)
       fetch_packet<NT>(N, tv, ts, meta_c.x, meta_c.y & 0x1ffffffu, (int)(meta_c.y >> 25), lead0,
-                       lane, lr_c);
+                       lane, lr_c & 63);
     }
     const int ncp = (t.ncoo + 255) >> 8; // COO packets of this tile
     Pkt<V> C;
@@ -464,7 +500,8 @@ __global__ void __launch_bounds__(BLOCK, 4)
       int cnt = (int)(meta_c.y >> 25);
       const unsigned long long leaders = ((unsigned long long)meta_c.w << 32) | meta_c.z;
       Pkt<V> A = N;
-      const int lr = lr_c; // leader rank of this lane in the current slice
+      const int lr = lr_c & 63; // leader rank of this lane in the current slice
+      const bool give = MODE == 0 && (lr_c & 64), take = MODE == 0 && (lr_c & 128);
       // ticket for the slice after next (its metadata is a scalar load that
       // lands long before it is needed)
       int s_nn = 0;
@@ -478,9 +515,9 @@ __global__ void __launch_bounds__(BLOCK, 4)
         info_c = pn < nvr ? in_ : 0u;
         dg_c = pn < nvr ? dn : V(0);
         const unsigned long long lead_n = ((unsigned long long)meta_n.w << 32) | meta_n.z;
-        lr_c = leader_rank(lead_n, L_n); // L_n was requested a slice ago
+        lr_c = leader_rank(lead_n, L_n & 63) | (L_n & 0xc0); // L_n was requested a slice ago
         fetch_packet<NT>(N, tv, ts, meta_n.x, meta_n.y & 0x1ffffffu, (int)(meta_n.y >> 25), lead_n,
-                         lane, lr_c);
+                         lane, lr_c & 63);
       }
       meta_c = meta_n;
       if (s_nn < nsl) meta_n = smeta[s_nn];
@@ -497,15 +534,19 @@ __global__ void __launch_bounds__(BLOCK, 4)
 
       int g = 0;
       Pkt<V> B;
+      auto consume = [&](const Pkt<V> &pk, bool act) {
+        if (MODE == 0) consume_combined<V, OFFB, DET>(pk, xl, yl, xi, acc, ny, act, give, take);
+        else if (act) consume_packet<V, MODE, OFFB, DET>(pk, xl, yl, xi, acc, ny);
+      };
       while (g + 2 < amax) { // steady state: two packets per trip, no copies
         const int cnt1 = __popcll(__ballot(a > g + 1));
         const uint32_t off1 = off + 4u * (uint32_t)cnt, soff1 = soff + slot_block(leaders, cnt);
         fetch_packet<NT>(B, tv, ts, off1, soff1, cnt1, leaders, lane, lr);
-        if (a > g) consume_packet<V, MODE, OFFB, DET>(A, xl, yl, xi, acc, ny);
+        consume(A, a > g);
         const int cnt2 = __popcll(__ballot(a > g + 2));
         const uint32_t off2 = off1 + 4u * (uint32_t)cnt1, soff2 = soff1 + slot_block(leaders, cnt1);
         fetch_packet<NT>(A, tv, ts, off2, soff2, cnt2, leaders, lane, lr);
-        if (a > g + 1) consume_packet<V, MODE, OFFB, DET>(B, xl, yl, xi, acc, ny);
+        consume(B, a > g + 1);
         g += 2;
         off = off2;
         soff = soff2;
@@ -515,10 +556,10 @@ __global__ void __launch_bounds__(BLOCK, 4)
         const int cnt1 = __popcll(__ballot(a > g + 1));
         fetch_packet<NT>(B, tv, ts, off + 4u * (uint32_t)cnt, soff + slot_block(leaders, cnt), cnt1,
                          leaders, lane, lr);
-        if (a > g) consume_packet<V, MODE, OFFB, DET>(A, xl, yl, xi, acc, ny);
-        if (a > g + 1) consume_packet<V, MODE, OFFB, DET>(B, xl, yl, xi, acc, ny);
+        consume(A, a > g);
+        consume(B, a > g + 1);
       } else if (amax - g == 1) {
-        if (a > g) consume_packet<V, MODE, OFFB, DET>(A, xl, yl, xi, acc, ny);
+        consume(A, a > g);
       }
       if (s_cur * 64 + lane < nvr) yl.add(r, (double)fma(dg, xi, acc));
     }
@@ -1351,6 +1392,7 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
     if (atoi(e) > 0) r.far_uses = atoi(e);
   if (const char *e = getenv("CFS_HIP_HYB")) r.hyb = atoi(e) != 0;
   if (const char *e = getenv("CFS_HIP_COST_MODEL")) r.cost_model = atoi(e) != 0;
+  if (const char *e = getenv("CFS_HIP_COMBINE")) r.combine_siblings = atoi(e) != 0;
   if (const char *e = getenv("CFS_HIP_DETERMINISTIC")) r.deterministic = atoi(e) != 0;
   if (r.deterministic) { // one kernel shape, no far entries (see YWin)
     r.hyb = false;

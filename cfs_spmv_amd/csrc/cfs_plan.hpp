@@ -70,6 +70,7 @@ struct Options {
   // any positive scale); empty = equal shares.
   std::vector<double> group_share;
   bool cost_model = true; // tiles / halo / dispatch wave in the cost of a group (ClusterCost)
+  bool combine_siblings = true; // leadlane bits 6 / 7: one y-window atomic per run of sibling lanes
   // Shards (nranks > 1): off-block entries are stored by BOTH ranks they touch and
   // processed one-sided (row side only): a row of the block also carries its
   // entries a_ri of rows r owned by higher ranks, and its entries left of the
@@ -938,6 +939,23 @@ template <typename V> struct Builder {
           for (int l = p1 - p0; l < kLanes; l++) { // unused lanes: own (empty) runs
             leaders |= 1ull << l;
             ll[l] = (uint8_t)l;
+          }
+          // Lanes that read the same slots add to the same y-window words.  A follower
+          // that sits right behind a lane of its group (its leader or another follower),
+          // inside the same row of 16 lanes, hands its products to that lane instead (DPP
+          // row shift in the kernel, runs of at most three lanes): bit 6 = "my products go
+          // to my left neighbour", bit 7 = "I take my right neighbour's".
+          if (opt.combine_siblings) {
+            int run = 0; // lanes already chained to the current head
+            bool cf[kLanes];
+            for (int l = 0; l < kLanes; l++) {
+              const bool chained = l > 0 && (l & 15) != 0 && (ll[l] & 63) != l && l < p1 - p0 &&
+                                   (ll[l] & 63) == (ll[l - 1] & 63) && run < 2;
+              cf[l] = chained;
+              run = chained ? run + 1 : 0;
+            }
+            for (int l = 0; l < kLanes; l++)
+              ll[l] = (uint8_t)((ll[l] & 63) | (cf[l] ? 64 : 0) | (l + 1 < kLanes && cf[l + 1] ? 128 : 0));
           }
           sm.soff_cnt0 |= cnt0 << 25;
           sm.leaders = leaders;
@@ -1930,7 +1948,7 @@ void decode_plan(const SymPlan<V> &P, std::vector<int32_t> &row,
         int nlead = 0;
         for (int l = 0; l < cnt; l++) {
           if ((sm.leaders >> l) & 1) nlead++;
-          const int Ld = ll[l];
+          const int Ld = ll[l] & 63;
           const int rank = __builtin_popcountll(sm.leaders & ((1ull << Ld) - 1));
           for (int j = 0; j < kPacket; j++)
             rows_out[r[l]].push_back({slot_col(ts[os + packet_slot_pos(rank, j)]),
