@@ -283,7 +283,7 @@ __device__ __forceinline__ void coo_update(const V *xl, const YWin<DET> &yl, V a
 // (second launch bound: 4 waves per SIMD must stay resident -- two 512-thread
 // workgroups, or one of 1 024, per CU -- i.e. at most 128 VGPRs; the persistent grid
 // is sized for exactly that residency)
-template <typename V, int BLOCK, int MODE, bool NT, bool OFFB, int U, bool DET = false>
+template <typename V, int BLOCK, int MODE, bool NT, bool OFFB, int U, bool DET = false, bool COMB = true>
 __global__ void __launch_bounds__(BLOCK, 4)
     cfs_sym_tile_kernel(const Tile *__restrict__ a_tiles, const Tile *__restrict__ a_gfirst,
                         const int2 *__restrict__ a_group_range,
@@ -501,7 +501,9 @@ __global__ void __launch_bounds__(BLOCK, 4)
       const unsigned long long leaders = ((unsigned long long)meta_c.w << 32) | meta_c.z;
       Pkt<V> A = N;
       const int lr = lr_c & 63; // leader rank of this lane in the current slice
-      const bool give = MODE == 0 && (lr_c & 64), take = MODE == 0 && (lr_c & 128);
+      // COMB: one atomic per run of sibling lanes (entry_combined); a schedule with few such
+      // runs -- one unknown per mesh node -- launches the plain instantiation
+      const bool give = MODE == 0 && COMB && (lr_c & 64), take = MODE == 0 && COMB && (lr_c & 128);
       // ticket for the slice after next (its metadata is a scalar load that
       // lands long before it is needed)
       int s_nn = 0;
@@ -535,7 +537,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
       int g = 0;
       Pkt<V> B;
       auto consume = [&](const Pkt<V> &pk, bool act) {
-        if (MODE == 0) consume_combined<V, OFFB, DET>(pk, xl, yl, xi, acc, ny, act, give, take);
+        if (MODE == 0 && COMB) consume_combined<V, OFFB, DET>(pk, xl, yl, xi, acc, ny, act, give, take);
         else if (act) consume_packet<V, MODE, OFFB, DET>(pk, xl, yl, xi, acc, ny);
       };
       while (g + 2 < amax) { // steady state: two packets per trip, no copies
@@ -930,6 +932,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int ablate_mode = 0; // cfs_hip_options.flags & 7 (timing-only ablations)
   bool nt_stream = true; // matrix stream larger than the Infinity Cache: non-temporal loads
   bool offblock = false; // some tile has one-sided (off-block) slots: mirrored shard
+  bool combine = true;   // enough sibling chains (>= 10 % of the lane-packets) for the combining kernel
   int64_t mirror_entries = 0;
   unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
   size_t lds_bytes = 0;
@@ -989,6 +992,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     if ((rc = strip.alloc((size_t)P.nhalo * sizeof(V)))) return rc;
     halo_slots = P.nhalo;
     offblock = P.onesided_slots > 0;
+    combine = P.chained_packets * 10 >= P.lane_packets && P.chained_packets > 0;
     mirror_entries = P.mirror_entries;
     stream_len = P.stream_len;
     slot_len = P.slot_len;
@@ -1038,8 +1042,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   }
 
   // the instantiation of the tile kernel this handle launches
-  template <int BLOCK> static const void *pick_kernel(int mode, bool nt, bool offb, int u, bool det) {
+  template <int BLOCK> static const void *pick_kernel(int mode, bool nt, bool offb, int u, bool det, bool comb) {
 #define CFS_K(M, N, O, UU) ((const void *)cfs_sym_tile_kernel<V, BLOCK, M, N, O, UU>)
+#define CFS_KP(N, O, UU) ((const void *)cfs_sym_tile_kernel<V, BLOCK, 0, N, O, UU, false, false>)
 #define CFS_KDET(N, O, UU) ((const void *)cfs_sym_tile_kernel<V, 512, 0, N, O, UU, true>)
     constexpr int UM = cfs_plan::kSlotsPerThread;
     switch (mode) {
@@ -1062,17 +1067,23 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
          {CFS_K(0, false, true, 3), CFS_K(0, false, true, 6), CFS_K(0, false, true, UM)}},
         {{CFS_K(0, true, false, 3), CFS_K(0, true, false, 6), CFS_K(0, true, false, UM)},
          {CFS_K(0, true, true, 3), CFS_K(0, true, true, 6), CFS_K(0, true, true, UM)}}};
+    static const void *const ptab[2][2][3] = { // plain: no sibling-combined atomics
+        {{CFS_KP(false, false, 3), CFS_KP(false, false, 6), CFS_KP(false, false, UM)},
+         {CFS_KP(false, true, 3), CFS_KP(false, true, 6), CFS_KP(false, true, UM)}},
+        {{CFS_KP(true, false, 3), CFS_KP(true, false, 6), CFS_KP(true, false, UM)},
+         {CFS_KP(true, true, 3), CFS_KP(true, true, 6), CFS_KP(true, true, UM)}}};
 #undef CFS_K
+#undef CFS_KP
 #undef CFS_KDET
-    return tab[nt ? 1 : 0][offb ? 1 : 0][u <= 3 ? 0 : (u <= 6 ? 1 : 2)];
+    return (comb ? tab : ptab)[nt ? 1 : 0][offb ? 1 : 0][u <= 3 ? 0 : (u <= 6 ? 1 : 2)];
   }
   const void *tile_kernel() {
     const int u = (P.lds_slots + P.block_threads - 1) / P.block_threads;
     switch (P.block_threads) {
-    case 256: return pick_kernel<256>(ablate_mode, nt_stream, offblock, u, false);
+    case 256: return pick_kernel<256>(ablate_mode, nt_stream, offblock, u, false, combine);
     case 512: return pick_kernel<512>(P.deterministic ? 0 : ablate_mode, nt_stream, offblock, u,
-                                      P.deterministic);
-    default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u, false);
+                                      P.deterministic, combine);
+    default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u, false, combine);
     }
   }
   int launch_tiles(V *y, const V *x, hipStream_t st) {

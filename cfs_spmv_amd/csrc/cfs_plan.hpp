@@ -259,6 +259,8 @@ template <typename V> struct SymPlan {
   int64_t mirror_entries = 0; // one-sided entries stored for rows of higher ranks
   int64_t onesided_slots = 0; // halo slots without a y window
   int64_t far_candidates = 0; // entries the first cut marked as far (before the final cut)
+  int64_t chained_packets = 0, lane_packets = 0; // packets of lanes that hand their products to a
+                                                 // sibling (leadlane bit 6) / of all lanes
   std::vector<int32_t> tile_rounds; // [T] packet rounds of a tile: sum over its slices of the
                                     // longest lane's packet count (issue cost, not bytes)
   std::string error;
@@ -954,8 +956,16 @@ template <typename V> struct Builder {
               cf[l] = chained;
               run = chained ? run + 1 : 0;
             }
-            for (int l = 0; l < kLanes; l++)
+            int64_t chained = 0, all = 0;
+            for (int l = 0; l < kLanes; l++) {
               ll[l] = (uint8_t)((ll[l] & 63) | (cf[l] ? 64 : 0) | (l + 1 < kLanes && cf[l + 1] ? 128 : 0));
+              if (l < p1 - p0) {
+                all += vr[p0 + l].a;
+                if (cf[l]) chained += vr[p0 + l].a;
+              }
+            }
+            __atomic_fetch_add(&P.chained_packets, chained, __ATOMIC_RELAXED);
+            __atomic_fetch_add(&P.lane_packets, all, __ATOMIC_RELAXED);
           }
           sm.soff_cnt0 |= cnt0 << 25;
           sm.leaders = leaders;
