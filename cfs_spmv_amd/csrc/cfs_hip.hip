@@ -932,7 +932,9 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int ablate_mode = 0; // cfs_hip_options.flags & 7 (timing-only ablations)
   bool nt_stream = true; // matrix stream larger than the Infinity Cache: non-temporal loads
   bool offblock = false; // some tile has one-sided (off-block) slots: mirrored shard
-  bool combine = true;   // enough sibling chains (>= 10 % of the lane-packets) for the combining kernel
+  bool combine_ok = false; // enough sibling chains (>= 10 % of the lane-packets) for the combining kernel
+  bool combine = false;    // ... and it is the one this handle launches
+  bool combine_forced = false;
   int64_t mirror_entries = 0;
   unsigned long long *dbg_buf = nullptr; // set only by cfs_hip_sym_debug_timeline
   size_t lds_bytes = 0;
@@ -992,7 +994,14 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     if ((rc = strip.alloc((size_t)P.nhalo * sizeof(V)))) return rc;
     halo_slots = P.nhalo;
     offblock = P.onesided_slots > 0;
-    combine = P.chained_packets * 10 >= P.lane_packets && P.chained_packets > 0;
+    // combining kernel: enough sibling chains, and a launch long enough for the longer
+    // dependency chain per entry to hide (measured: ldoor stand-in, 283 MB per launch,
+    // +3 %; 1/8 shards, 89-131 MB, -8 %); tune() times both where it may (sym_create)
+    combine_ok = P.chained_packets * 10 >= P.lane_packets && P.chained_packets > 0;
+    combine = combine_ok && P.stream_len * (int64_t)sizeof(V) + P.slot_len * 2 >= (int64_t)200 * 1000 * 1000;
+    combine_forced = false;
+    if (const char *e = getenv("CFS_HIP_COMBINE")) // developer knob: 2 = the combining kernel whatever the size
+      if (atoi(e) == 2) combine = combine_ok, combine_forced = true;
     mirror_entries = P.mirror_entries;
     stream_len = P.stream_len;
     slot_len = P.slot_len;
@@ -1533,13 +1542,42 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     (void)hipEventDestroy(b);
     return r2;
   };
+  auto ensure_xy = [&]() -> int {
+    if (xb.p) return 0;
+    int r2;
+    if ((r2 = xb.alloc((size_t)n * sizeof(V))) || (r2 = yb.alloc((size_t)m->rows() * sizeof(V)))) return r2;
+    (void)hipMemset(xb.p, 0x3f, xb.bytes); // small positive values
+    return 0;
+  };
+  // which instantiation of the tile kernel (sibling-combined atomics or plain) a handle
+  // launches: same schedule, same arrays -- time ten SpMVs of each, twice
+  auto choose_kernel = [&](SymMatrix<V> *h) -> int {
+    if (!h->combine_ok || h->combine_forced) return 0;
+    int r2 = ensure_xy();
+    if (r2) return r2;
+    const bool dflt = h->combine; // the size rule's choice (upload()): kept unless the other
+    float t[2] = {1e30f, 1e30f};  // instantiation is clearly -- 2 % -- faster
+    for (int round = 0; round < 2; round++)
+      for (int c = 0; c < 2; c++) {
+        float ms = 0;
+        h->combine = c == 1;
+        if (time_spmv(h, &ms)) {
+          h->combine = dflt;
+          return 0;
+        }
+        t[c] = std::min(t[c], ms);
+      }
+    h->combine = t[dflt ? 0 : 1] < 0.98f * t[dflt ? 1 : 0] ? !dflt : dflt;
+    if (getenv("CFS_PLAN_VERBOSE"))
+      fprintf(stderr, "[cfs_hip] tile kernel: plain %.1f us, sibling-combined atomics %.1f us\n", t[0] * 100.0,
+              t[1] * 100.0);
+    return 0;
+  };
   auto try_alternative = [&](cfs_plan::Options &po2, cfs_plan::ScheduleSpace<V> *sp,
                              const char *what, int forced = -1) -> int {
-    if (!xb.p) {
-      int r2;
-      if ((r2 = xb.alloc((size_t)n * sizeof(V))) || (r2 = yb.alloc((size_t)m->rows() * sizeof(V))))
-        return r2;
-      (void)hipMemset(xb.p, 0x3f, xb.bytes); // small positive values
+    {
+      int r2 = ensure_xy();
+      if (r2) return r2;
     }
     auto *alt = new SymMatrix<V>();
     alt->value_bytes = (int)sizeof(V);
@@ -1549,7 +1587,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     bool ok = query_residency<V>(po2) == 0 &&
               cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
                                       nranks > 1 ? row_splits : nullptr, po2, alt->P, sp) &&
-              alt->upload() == 0;
+              alt->upload() == 0 && choose_kernel(alt) == 0;
     for (int round = 0; ok && round < 3; round++) {
       float a = 0, b = 0;
       ok = time_spmv(m, &a) == 0 && time_spmv(alt, &b) == 0;
@@ -1572,6 +1610,10 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     }
     return 0;
   };
+  if (tuning && (rc = choose_kernel(m))) {
+    delete m;
+    return rc;
+  }
   // (natural-order schedules are tried too: a 1/8 row block of the Flan stand-in runs 11 %
   // faster with 256 workgroups of 1 024 threads -- a third less halo, half as many window
   // phases per CU -- while pwtk, ldoor and Queen stay with the default)
