@@ -1550,14 +1550,14 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     return 0;
   };
   // which instantiation of the tile kernel (sibling-combined atomics or plain) a handle
-  // launches: same schedule, same arrays -- time ten SpMVs of each, twice
+  // launches: same schedule, same arrays -- time ten SpMVs of each, three times
   auto choose_kernel = [&](SymMatrix<V> *h) -> int {
     if (!h->combine_ok || h->combine_forced) return 0;
     int r2 = ensure_xy();
     if (r2) return r2;
     const bool dflt = h->combine; // the size rule's choice (upload()): kept unless the other
-    float t[2] = {1e30f, 1e30f};  // instantiation is clearly -- 2 % -- faster
-    for (int round = 0; round < 2; round++)
+    float t[2] = {1e30f, 1e30f};  // instantiation is clearly -- 3 %, best of three -- faster
+    for (int round = 0; round < 3; round++)
       for (int c = 0; c < 2; c++) {
         float ms = 0;
         h->combine = c == 1;
@@ -1567,7 +1567,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
         }
         t[c] = std::min(t[c], ms);
       }
-    h->combine = t[dflt ? 0 : 1] < 0.98f * t[dflt ? 1 : 0] ? !dflt : dflt;
+    h->combine = t[dflt ? 0 : 1] < 0.97f * t[dflt ? 1 : 0] ? !dflt : dflt;
     if (getenv("CFS_PLAN_VERBOSE"))
       fprintf(stderr, "[cfs_hip] tile kernel: plain %.1f us, sibling-combined atomics %.1f us\n", t[0] * 100.0,
               t[1] * 100.0);
