@@ -2128,6 +2128,31 @@ static int plan_check(int n, const int *rowptr, const int *colind, const V *valu
     if (mv + mc != P.nnz_low + P.mirror_entries - P.far_entries || mf != 2 * P.far_entries) bad++;
     if (md > (int64_t)(P.row_end - P.row_begin)) bad++;
   }
+  // (1c) sibling chains (leadlane bits 6 / 7), what entry_combined relies on: a lane that
+  // hands its products to its left neighbour is a follower, shares that neighbour's group
+  // and row of 16 lanes, has no more packets than it; runs hold at most three lanes; bit 7
+  // of a lane mirrors bit 6 of the next one
+  for (const Tile &t : P.tiles)
+    for (int sidx = 0; sidx < t.nslices; sidx++) {
+      const uint8_t *ll = P.leadlane.data() + (size_t)(t.slice_base + sidx) * cfs_plan::kLanes;
+      const int p0 = sidx * cfs_plan::kLanes;
+      auto packets = [&](int l) {
+        return p0 + l < (int)t.nvrows ? (int)(P.rowinfo[t.vrow_off + p0 + l] >> 16) : 0;
+      };
+      int run = 0;
+      for (int l = 0; l < cfs_plan::kLanes; l++) {
+        const bool give = ll[l] & 64, take = ll[l] & 128;
+        if (give) {
+          run++;
+          if (l == 0 || (l & 15) == 0 || (ll[l] & 63) == l || (ll[l] & 63) != (ll[l - 1] & 63) ||
+              packets(l) > packets(l - 1) || run > 2)
+            bad++;
+        } else {
+          run = 0;
+        }
+        if (take != (l + 1 < cfs_plan::kLanes && (ll[l + 1] & 64))) bad++;
+      }
+    }
   // (2) fold + send indices cover every strip entry exactly once and point at
   // a strip entry whose column is the destination row
   {
