@@ -10,6 +10,8 @@
   * y is fully overwritten (poisoned before every call).
 
 Tolerances are relative to max(|y|, sum_j |a_ij||x_j|) as in test_gpu_parity.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -46,8 +48,8 @@ def test_full_size_properties(name, dtype, mode):
     assert st["nnz_full"] == rp[-1]
     if mode != "x4":
         assert st["nnz_low"] == low
-    if mode == "hyb":
-        assert st["far_entries"] > 0
+    if mode == "hyb" and os.environ.get("CFS_HIP_DETERMINISTIC", "0") == "0":
+        assert st["far_entries"] > 0  # (a forced deterministic build has no far entries)
     if mode == "det":
         # fixed-point accumulation carries 2^-67 of the tile's scale per product
         # (DESIGN.md section 2): the fp32 / fp64 tolerances below hold unchanged
