@@ -10,6 +10,10 @@
 #define CFS_SPARSE_MATRIX_HPP
 
 #include <cstddef>
+// <random> and <string> are part of what this header gives its includers in the
+// reference (include/matrix/sparse_matrix.hpp:4-5): the unmodified drivers use
+// random_device / mt19937 through it (bench_spmv_mmf.cpp:123-125).
+#include <random>
 #include <string>
 
 #include "cfs_config.hpp"
@@ -29,8 +33,9 @@ public:
   //   Format::csr   every stored entry, general CSR kernel
   //   Format::sss   lower triangle + diagonal when the FILE is symmetric; a general
   //                 file silently becomes csr (csr_matrix.tpp:13-19)
-  //   Format::hyb   accepted, treated as sss (the reference's HYB variant asserts in
-  //                 its default multi-threaded build)
+  //   Format::hyb   sss with the far entries kept apart (CFS_HIP_FLAG_HYB, src/csr.cpp;
+  //                 the reference's split_by_bandwidth, csr_matrix.tpp:312-401, which
+  //                 asserts in its default multi-threaded build -- a working feature here)
   //   Platform::cpu refused with an error: this build has no CPU path
   static SparseMatrix<IndexT, ValueT> *create(const std::string &filename,
                                               Format format = Format::csr,

@@ -26,7 +26,8 @@ enum class Kernel { SpDMV };
 enum class Tuning { None, Aggressive };
 
 // storage asked for at create(): csr = every stored entry; sss = symmetric, lower
-// triangle + diagonal; hyb = treated as sss here; none = unset
+// triangle + diagonal; hyb = sss whose single-use halo entries leave the tile format
+// (far entries, CFS_HIP_FLAG_HYB); none = unset
 enum class Format { none, csr, sss, hyb };
 
 // ceil(a / b) for positive ints (partition sizes)
