@@ -44,3 +44,34 @@ def test_bench_does_not_relaunch_inside_torchrun(monkeypatch):
     except Exception:
         pass  # no GPU / no process group here: irrelevant
     assert not called
+
+
+def test_watchdog_prints_the_line_and_exits_nonzero(tmp_path):
+    """a stalled exchange form (a collective that never returns) must end bench.py with a
+    NON-ZERO exit code after the contract line was printed -- rc 0 would hide the hang from
+    torchrun and the driver.  The stall is a sleeping callable under the same
+    run_guarded() the N > 1 path uses; no GPU, no process group."""
+    code = (
+        "import sys, time, json; sys.path.insert(0, %r); import bench\n"
+        "out = {'metric': 'm', 'value': 1.0}\n"
+        "def on_timeout():\n"
+        "    out['exchange_forms'] = {'none': 0.1, 'others': 'timed out'}\n"
+        "    print(json.dumps(out), flush=True)\n"
+        "bench.run_guarded(lambda: time.sleep(60), 0.5, on_timeout)\n"
+        "print('NOT REACHED')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    sys.path.insert(0, ROOT)
+    import bench
+    assert r.returncode == bench.WATCHDOG_EXIT != 0, (r.returncode, r.stderr[-500:])
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and "NOT REACHED" not in r.stdout
+    import json
+    assert json.loads(lines[0])["exchange_forms"]["others"] == "timed out"
+
+
+def test_watchdog_is_silent_when_the_forms_return():
+    sys.path.insert(0, ROOT)
+    import bench
+    fired = []
+    assert bench.run_guarded(lambda: 42, 30.0, lambda: fired.append(1)) == 42
+    assert not fired
