@@ -76,6 +76,9 @@ def parse():
                          "GPU (what every rank of the driver's N-GPU run executes per step; no "
                          "process group).  value / roofline then refer to that block")
     ap.add_argument("--shard-rank", type=int, default=0)
+    ap.add_argument("--format", default="sss", choices=["sss", "csr"],
+                    help="sss (default): the symmetric hot path.  csr: Format::csr -- every stored entry "
+                         "through the general CSR kernel (cpu_mv's role, csr_matrix.tpp:2683-2704), N = 1")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the tile kernel with HIP events on every n-th timed step")
     return ap.parse_args()
@@ -157,6 +160,114 @@ def cpu_baseline(n, rp, ci, va, x_host, nnz_full, loops, threads, bound):
                 "effective_GBps": round((nnz_full * (4 + s) + n * (4 + 2 * s)) / dt_csr / 1e9, 1)},
         "effective_GBps": round(((nnz_full - n) // 2 * (4 + s) + n * (4 + 3 * s)) / dt / 1e9, 1),
     }
+
+
+def bench_csr(args, cfs, lib, n, rp, ci, va, x_host, nnz_full, dev, t_dt, data_kind, source, ncpus):
+    """Format::csr: one step = y <- A x over EVERY stored entry with the general CSR kernel
+    (cfs_csr_stream_kernel; the reference's cpu_mv, csr_matrix.tpp:2683-2704 -- the ground truth
+    of its own self-check, test/test_spmv_mmf.cpp:85-89).  Same protocol and line as the
+    symmetric path; algorithmic bytes per launch = nnz*(4+s) + n*(4+2s): colind + values, rowptr,
+    x once, y once."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from cfs_spmv_amd import _lib
+    t0 = time.time()
+    A = cfs.CsrMatrix(n, n, rp, ci, va)
+    preproc = time.time() - t0
+    x = torch.from_numpy(x_host).to(dev)
+    y = torch.full((n,), float("nan"), dtype=t_dt, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    f = lib.cfs_hip_csr_spmv_async
+    hA, yp, xp, stp = A._h, C.c_void_p(y.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(stream)
+
+    def step():
+        rc = f(hA, yp, xp, stp)
+        if rc != 0:
+            _lib.check(rc)
+
+    def new_event():
+        e = C.c_void_p()
+        _lib.check(lib.cfs_hip_event_create(C.byref(e)))
+        return e
+    K = args.steps
+    every = max(1, min(args.event_every, K // 10 if K >= 10 else 1))
+    sampled = [i for i in range(K) if i % every == 0]
+    ev0 = {i: new_event() for i in sampled}
+    ev1 = {i: new_event() for i in sampled}
+    t_pre = time.perf_counter()
+    while time.perf_counter() - t_pre < 0.030:
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        if i in ev0:
+            _lib.check(lib.cfs_hip_event_record(ev0[i], stream))
+            step()
+            _lib.check(lib.cfs_hip_event_record(ev1[i], stream))
+        else:
+            step()
+    torch.cuda.synchronize()
+    ms_per_step = (time.perf_counter() - t0) / K * 1e3
+    ms = C.c_float()
+    tot = 0.0
+    for i in sampled:
+        _lib.check(lib.cfs_hip_event_elapsed_ms(ev0[i], ev1[i], C.byref(ms)))
+        tot += ms.value
+    kern_ms = tot / len(sampled)
+    for e in list(ev0.values()) + list(ev1.values()):
+        lib.cfs_hip_event_destroy(e)
+    # self-check against the symmetric path (another kernel, another format) on the same x
+    S = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=32))
+    y2 = torch.empty(n, dtype=t_dt, device=dev)
+    S.dense_vector_multiply(y2, x)
+    torch.cuda.synchronize()
+    scale = torch.maximum(y2.abs(), torch.tensor(1.0, dtype=t_dt, device=dev))
+    err = float(((y - y2).abs() / scale).max().item())
+    S.close()
+    if not err < (1e-9 if args.dtype == "f64" else 1e-3):
+        raise SystemExit(f"self-check failed: max scaled |y_csr - y_sss| = {err}")
+    s_ = va.itemsize
+    form, meas = C.c_int(), C.c_int()
+    _lib.check(lib.cfs_hip_csr_kernel_form(A._h, C.byref(form), C.byref(meas)))
+    kname = "cfs_csr_wave_kernel" if form.value == 1 else "cfs_csr_stream_kernel"
+    alg = int(nnz_full * (4 + s_) + n * (4 + 2 * s_))
+    achieved = alg / (kern_ms * 1e-3) / 1e9
+    out = {
+        "metric": f"fp{s_ * 8} general CSR SpMV GFLOP/s", "value": round(2.0 * nnz_full / (ms_per_step * 1e-3) / 1e9, 2),
+        "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": args.dtype, "data": data_kind,
+        "config": {"workload": f"{source}: n={n}, nnz_full={nnz_full}, general CSR SpMV y=Ax over every "
+                               f"stored entry (Format::csr)", "format": "csr",
+                   "algorithmic_bytes_per_spmv": alg,
+                   "effective_GBps_whole_step": round(alg / (ms_per_step * 1e-3) / 1e9, 1),
+                   "preproc_s": round(preproc, 2),
+                   "kernel_form": ("wave" if form.value == 1 else "block") +
+                                  (" (pinned by CFS_HIP_CSR_KERNEL)" if os.environ.get("CFS_HIP_CSR_KERNEL")
+                                   else " (the faster of the two forms, measured at the first SpMV)")},
+        "roofline": {"bound": "hbm", "kernel": kname,
+                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel_ms": round(kern_ms, 5), "kernel_samples": len(sampled),
+                     "algorithmic_bytes_per_launch": alg,
+                     "hbm_frac_of_achievable_if_traffic_equals_algorithmic":
+                         round(achieved / HBM_ACHIEVABLE_GBS, 4)},
+    }
+    if not args.no_cpu_baseline:
+        try:
+            cb = cpu_baseline(n, rp, ci, va, x_host, nnz_full, args.cpu_loops, ncpus, args.cpu_bind)
+            out["cpu_baseline"] = dict(cb["csr"], cores=cb["cores"], kind="port",
+                                       sample=cb["sample"] + " (this line quotes the plain-CSR leg)")
+        except Exception as e:
+            out["cpu_baseline"] = {"value": None, "unit": "GFLOP/s", "cores": 0, "kind": "port",
+                                   "sample": f"failed: {e}"}
+    A.close()
+    print(json.dumps(out), flush=True)
 
 
 def time_other_forms(args, cfs, A, sh, n, rp, ci, va, N, rank, rs, dev, opt, backend, x, y,
@@ -350,6 +461,11 @@ def main():
     x_host = synth.make_x(n, 42, np_dt)
     opt = cfs.make_options(max_slots=args.max_slots, block_threads=args.block,
                            flags=args.flags | (32 if args.tuning == "none" else 0))
+
+    if args.format == "csr":
+        if N != 1:
+            raise SystemExit("--format csr runs on one GPU")
+        return bench_csr(args, cfs, lib, n, rp, ci, va, x_host, nnz_full, dev, t_dt, data_kind, source, ncpus)
 
     t0 = time.time()
     rs = None

@@ -4,7 +4,7 @@
 // (bench/bench_spmv_mmf.cpp:41-45, :139-173):
 //     bench_spmv_mmf <mmf_file> <format>(0: CSR, 1: SSS, 2: HYB) <iterations>
 //     matrix: <file> format: <CSR|SSS|HYB> preproc(sec): .. t(sec): .. gflops/s: ..
-//     threads: .. size(MB): ..            [+ gbytes/s: .. hbm_pct: .. gpus: ..]
+//     threads: .. size(MB): ..            [+ gbytes/s: .. hbm_pct: .. gpus: .. devices: ..]
 // gflops/s = loops * 2 * nnz / t with nnz the expanded count (:168).
 // x and y live in Platform::gpu memory during the timed loop (SURVEY.md
 // section 7, "x/y residency"): they are filled on the host exactly as the
@@ -101,12 +101,16 @@ int main(int argc, char **argv) {
   const double bytes = A->symmetric() ? nnz_low * (4 + s) + M * (4 + 3 * s)
                                       : nnz * (4 + s) + M * (4 + s) + N * s;
   const double gbs = bytes * loops * 1.e-9 / compute_time;
+  // the peak is that of the DISTINCT devices the shards run on (several shards may share a
+  // device: CFS_NUM_GPUS=4 on a one-GPU box is four shards of one 8 TB/s memory)
+  const int visible = get_num_devices();
+  const int ndev = ngpus < 1 ? 1 : (visible > 0 && ngpus > visible ? visible : ngpus);
   char *path = strdup(mmf_file.c_str());
   cout << setprecision(4) << "matrix: " << basename(path) << " format: " << names[fmt]
        << " preproc(sec): " << preproc_time << " t(sec): " << compute_time / loops
        << " gflops/s: " << gflops << " threads: " << nthreads
        << " size(MB): " << A->size() / (float)(1024 * 1024) << " gbytes/s: " << gbs
-       << " hbm_pct: " << 100.0 * gbs / (8000.0 * ngpus) << " gpus: " << ngpus << endl;
+       << " hbm_pct: " << 100.0 * gbs / (8000.0 * ndev) << " gpus: " << ngpus << " devices: " << ndev << endl;
   free(path);
 
   delete A;

@@ -48,15 +48,16 @@ class PlanReport(C.Structure):
 # every symbol include/cfs_hip.h declares (tests check the .so exports them all)
 SYMBOLS = [
     "cfs_hip_abi_version", "cfs_hip_last_error", "cfs_hip_device_count", "cfs_hip_init",
-    "cfs_hip_current_device", "cfs_hip_pinned_owns", "cfs_hip_pinned_pool_stats", "cfs_hip_default_stream", "cfs_hip_synchronize", "cfs_hip_alloc", "cfs_hip_free",
+    "cfs_hip_current_device", "cfs_hip_runtime_bound", "cfs_hip_pinned_owns", "cfs_hip_pinned_pool_stats", "cfs_hip_default_stream", "cfs_hip_synchronize", "cfs_hip_alloc", "cfs_hip_free",
     "cfs_hip_memcpy", "cfs_hip_memset", "cfs_hip_sym_create_f64", "cfs_hip_sym_create_f32",
     "cfs_hip_sym_create_shard_f64", "cfs_hip_sym_create_shard_f32",
-    "cfs_hip_sym_create_multi_f64", "cfs_hip_sym_create_multi_f32", "cfs_hip_sym_num_gpus", "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_update_values_f64", "cfs_hip_sym_update_values_f32", "cfs_hip_sym_spmv",
+    "cfs_hip_sym_create_multi_f64", "cfs_hip_sym_create_multi_f32", "cfs_hip_comm_create", "cfs_hip_comm_info", "cfs_hip_comm_destroy", "cfs_hip_comm_reduce_scatter",
+    "cfs_hip_comm_allgather", "cfs_hip_comm_wait_consumed", "cfs_hip_sym_num_gpus", "cfs_hip_sym_multi_set_xmode", "cfs_hip_sym_multi_devices", "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_update_values_f64", "cfs_hip_sym_update_values_f32", "cfs_hip_sym_spmv",
     "cfs_hip_sym_spmv_async", "cfs_hip_sym_shard_send_counts", "cfs_hip_sym_shard_send_rows",
     "cfs_hip_sym_shard_set_recv", "cfs_hip_sym_spmv_local_async",
-    "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_debug_group_features", "cfs_hip_sym_plan_check_f64",
+    "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_digest", "cfs_hip_sym_debug_plan_note", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_debug_group_features", "cfs_hip_sym_plan_check_f64",
     "cfs_hip_sym_plan_check_f32", "cfs_hip_sym_plan_send_info_f64", "cfs_hip_csr_create_f64", "cfs_hip_csr_create_f32",
-    "cfs_hip_csr_spmv", "cfs_hip_csr_spmv_async", "cfs_hip_csr_destroy",
+    "cfs_hip_csr_spmv", "cfs_hip_csr_spmv_async", "cfs_hip_csr_destroy", "cfs_hip_csr_kernel_form",
     "cfs_hip_event_create", "cfs_hip_event_record", "cfs_hip_event_elapsed_ms",
     "cfs_hip_event_destroy",
 ]
@@ -107,6 +108,16 @@ def load():
         C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, C.POINTER(Options), vp, vp, C.c_int, ip]
     lib.cfs_hip_sym_balanced_splits.argtypes = [C.c_int, vp, vp, C.c_int, vp]
     lib.cfs_hip_sym_num_gpus.argtypes = [vp, ip]
+    if hasattr(lib, "cfs_hip_comm_create"):
+        lib.cfs_hip_comm_create.argtypes = [C.c_int, vp, C.c_int, C.POINTER(vp)]
+        lib.cfs_hip_comm_info.argtypes = [vp, ip, ip]
+        lib.cfs_hip_comm_destroy.argtypes = [vp]
+        lib.cfs_hip_comm_reduce_scatter.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
+        lib.cfs_hip_comm_allgather.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp]
+        lib.cfs_hip_comm_wait_consumed.argtypes = [vp, C.c_int, vp]
+    if hasattr(lib, "cfs_hip_sym_multi_set_xmode"):
+        lib.cfs_hip_sym_multi_set_xmode.argtypes = [vp, C.c_int]
+        lib.cfs_hip_sym_multi_devices.argtypes = [vp, vp, C.c_int, ip]
     lib.cfs_hip_sym_destroy.argtypes = [vp]
     lib.cfs_hip_sym_update_values_f64.argtypes = [vp, vp, C.c_longlong]
     lib.cfs_hip_sym_update_values_f32.argtypes = [vp, vp, C.c_longlong]
@@ -120,10 +131,15 @@ def load():
     lib.cfs_hip_sym_spmv_phases_async.argtypes = [vp, vp, vp, vp, C.c_int, vp]
     lib.cfs_hip_sym_get_stats.argtypes = [vp, C.POINTER(SymStats)]
     lib.cfs_hip_sym_debug_timeline.argtypes = [vp, vp, vp, vp, C.c_int, ip]
+    if hasattr(lib, "cfs_hip_sym_debug_digest"):  # (absent from older builds loaded through CFS_HIP_LIB)
+        lib.cfs_hip_sym_debug_digest.argtypes = [vp, vp, C.c_int]
+        lib.cfs_hip_sym_debug_plan_note.argtypes = [vp, C.c_char_p, C.c_int]
     lib.cfs_hip_sym_debug_group_features.argtypes = [vp, vp, C.c_int, ip]
     lib.cfs_hip_csr_spmv.argtypes = [vp, vp, vp]
     lib.cfs_hip_csr_spmv_async.argtypes = [vp, vp, vp, vp]
     lib.cfs_hip_csr_destroy.argtypes = [vp]
+    if hasattr(lib, "cfs_hip_csr_kernel_form"):
+        lib.cfs_hip_csr_kernel_form.argtypes = [vp, ip, ip]
     lib.cfs_hip_event_create.argtypes = [C.POINTER(vp)]
     lib.cfs_hip_event_record.argtypes = [vp, vp]
     lib.cfs_hip_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]

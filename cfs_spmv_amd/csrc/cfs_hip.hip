@@ -20,6 +20,7 @@
 #include "cfs_hip.h"
 #include "cfs_plan.hpp"
 #include "cfs_runtime.hpp"
+#include "cfs_comm.hpp"
 
 using cfs_plan::SymPlan;
 using cfs_plan::Tile;
@@ -485,9 +486,17 @@ __global__ void __launch_bounds__(BLOCK, 4)
     double det_unscale = 1.0;
     if (DET) {
       // |a| < 2^aexp (plan), |x| < 2^(E - 1022) (window), 12 bits for the longest row sum
-      const int e = t.aexp + (__builtin_amdgcn_readfirstlane(cfs_ticket[2 + det_parity]) - 1022) + 12;
+      const int xe = __builtin_amdgcn_readfirstlane(cfs_ticket[2 + det_parity]);
+      const int e = t.aexp + (xe - 1022) + 12;
       yl.inv = pow2_double(40 - e);
       det_unscale = pow2_double(e - 40);
+      // a NaN / Inf in the window of x (exponent field 2047) or among the tile's values (plan:
+      // aexp = kAexpNonFinite) has no fixed-point image: every row of the tile reads NaN,
+      // as the floating-point path would propagate it -- never plausible finite garbage
+      if (xe >= 2047 || t.aexp >= cfs_plan::kAexpNonFinite) {
+        yl.inv = 0.0;
+        det_unscale = __longlong_as_double(0x7ff8000000000000ll);
+      }
       det_parity ^= 1;
       if (tid == 0) cfs_ticket[2 + det_parity] = 0; // the next tile's word (see the header comment)
     }
@@ -793,6 +802,115 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// general CSR, wave-stream form: every WAVE walks its own sequence of chunks
+// -- whole rows, at most kCwNnz nonzeros and kCwRows rows, cut on the host: a 16-byte
+// descriptor per chunk instead of row-pointer searches -- with no workgroup barrier at
+// all.  A wave keeps the NEXT chunk's colind / values loads in flight (a second register
+// set, unconditional clamped loads: exact vmcnt bookkeeping) while it gathers x for the
+// current one, stages the products in its private 4 KiB of LDS and sums the rows with
+// 64 / rows lanes each: the 16-20 resident waves of a CU are each in a different phase
+// and their streams never stop.  Rows longer than a chunk are summed by
+// cfs_csr_longrow_kernel, a workgroup each.  Which of the two forms a handle launches is
+// MEASURED when it is created (five SpMVs each): on the Flan stand-in they are within 5 % of
+// each other and the order changes from box to box (block / wave: 279 / 297 us on one,
+// 296 / 281 us on another).  (Reference: cpu_mv, csr_matrix.tpp:2683-2704.)
+constexpr int kCwNnz = 512; // products per chunk (8 per lane)
+constexpr int kCwRows = 63; // rows per chunk (row pointers: one per lane, + the end)
+template <typename V>
+__global__ void __launch_bounds__(256)
+    cfs_csr_wave_kernel(const int4 *__restrict__ cd, int nchunks, const int32_t *__restrict__ rowptr,
+                        const int32_t *__restrict__ colind, const V *__restrict__ values,
+                        const V *__restrict__ x, V *__restrict__ y) {
+  __shared__ V prod[4][kCwNnz];
+  constexpr int PER = kCwNnz / 64;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  V *pl = prod[w];
+  const int nw = gridDim.x * 4;
+  int k = blockIdx.x * 4 + w;
+  if (k >= nchunks) return;
+  int4 dn = cd[k]; // {first row, rows, first nonzero, nonzeros}
+  V vn[PER];
+  int cn[PER], rpn;
+  auto fetch = [&](const int4 &dsc) {
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int q = dsc.z + min(lane + u * 64, max(dsc.w, 1) - 1);
+      vn[u] = __builtin_nontemporal_load(values + q);
+      cn[u] = __builtin_nontemporal_load(colind + q);
+    }
+    rpn = rowptr[dsc.x + min(lane, dsc.y)] - dsc.z;
+  };
+  fetch(dn);
+  while (true) {
+    const int4 dc = dn;
+    V v[PER];
+    int c[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) v[u] = vn[u], c[u] = cn[u];
+    const int rp = rpn;
+    const int kn = k + nw;
+    dn = cd[min(kn, nchunks - 1)]; // (the last chunk once more at the end of a wave's walk: unconditional loads)
+    fetch(dn);
+    V xx[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) xx[u] = x[c[u]];
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+      if (lane + u * 64 < dc.w) pl[lane + u * 64] = v[u] * xx[u];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // rows: 64 / (rows rounded up to a power of two) lanes each
+    int lpr = 64;
+    while (lpr > 1 && 64 / lpr < dc.y) lpr >>= 1;
+    const int r = lane / lpr, sub = lane & (lpr - 1);
+    const int b0 = __shfl(rp, min(r, 63)), e0 = __shfl(rp, min(r + 1, 63));
+    V acc = V(0);
+    if (r < dc.y)
+      for (int j = b0 + sub; j < e0; j += lpr) acc += pl[j];
+    for (int o = lpr >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (sub == 0 && r < dc.y) y[dc.x + r] = acc;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (kn >= nchunks) break;
+    k = kn;
+  }
+}
+// rows longer than a chunk: one workgroup per row
+template <typename V>
+__global__ void __launch_bounds__(256)
+    cfs_csr_longrow_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ rowptr,
+                           const int32_t *__restrict__ colind, const V *__restrict__ values,
+                           const V *__restrict__ x, V *__restrict__ y) {
+  __shared__ V part[256];
+  const int tid = threadIdx.x, r = rows[blockIdx.x];
+  V acc = V(0);
+  for (int j = rowptr[r] + tid; j < rowptr[r + 1]; j += 256) acc = fma(values[j], x[colind[j]], acc);
+  part[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) part[tid] += part[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) y[r] = part[0];
+}
+
+// the dense form of the exchange (north-star: reduce-scatter of the off-block contributions):
+// a shard's packed contributions go to their slot of a zeroed vector of nranks equal blocks ...
+template <typename V>
+__global__ void __launch_bounds__(256)
+    cfs_scatter_pos_kernel(V *__restrict__ dense, const int32_t *__restrict__ pos, const V *__restrict__ packed, int m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) dense[pos[i]] = packed[i];
+}
+// ... and the block a rank receives is added to its rows
+template <typename V>
+__global__ void __launch_bounds__(256) cfs_add_rows_kernel(V *__restrict__ y, const V *__restrict__ add, int m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < m) y[i] += add[i];
+}
+
 // ---------------------------------------------------------------------------
 // host objects
 // ---------------------------------------------------------------------------
@@ -913,6 +1031,7 @@ struct cfs_hip_sym_s {
   // values_dev: the caller's full CSR value array (same pattern as at create), on this device
   virtual int update_values(const void *values_dev, long long nnz, hipStream_t st) = 0;
   int device = 0; // the device this handle's arrays live on (current device at create)
+  std::string plan_note; // why the device builder handed the schedule to the host builder ("" = it did not)
   HostStage stage; // host-pointer callers
   // the last (y, x) pair whose placement was validated (async entry points)
   const void *ok_x = nullptr, *ok_y = nullptr;
@@ -940,23 +1059,13 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   size_t lds_bytes = 0;
   int64_t halo_slots = 0, stream_len = 0, slot_len = 0, nslices = 0, coo_len = 0, far_len = 0, far_entries = 0;
 
+  bool device_built = false; // the schedule was built by cfs_devplan.hpp (arrays never on the host)
+
   int upload() {
     int rc;
 #define UP(buf, vec)                                                          \
   if ((rc = buf.upload(vec.data(), vec.size() * sizeof(vec[0])))) return rc;
     UP(tiles, P.tiles)
-    { // per launch slot: first tile + tile range of the group that runs there
-      const int G = (int)P.group_first.size();
-      std::vector<Tile> gf(G);
-      std::vector<int2> gr(G);
-      for (int sl = 0; sl < G; sl++) {
-        const int g = (int)P.launch_order.size() == G ? P.launch_order[sl] : sl;
-        gf[sl] = P.group_first[g];
-        gr[sl] = make_int2(P.group_ptr[g], P.group_ptr[g + 1]);
-      }
-      UP(gfirst, gf)
-      UP(group_ptr, gr)
-    }
     UP(slot_col, P.slot_col)
     UP(rowinfo, P.rowinfo)
     UP(diag, P.diag)
@@ -991,6 +1100,48 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     UP(send_ptr, P.send_ptr)
     UP(send_idx, P.send_idx)
 #undef UP
+    if ((rc = finish_setup((int64_t)P.slice_meta.size()))) return rc;
+    // release the big host arrays; keep the small metadata
+    cfs_plan::release_async(P.vals);
+    cfs_plan::release(P.slots);
+    std::vector<uint8_t>().swap(P.leadlane);
+    std::vector<V>().swap(P.cvals);
+    std::vector<uint16_t>().swap(P.crows);
+    std::vector<uint16_t>().swap(P.ccols);
+    std::vector<V>().swap(P.fvals);
+    std::vector<uint16_t>().swap(P.frows);
+    std::vector<int32_t>().swap(P.fcols);
+    std::vector<V>().swap(P.diag);
+    std::vector<uint32_t>().swap(P.rowinfo);
+    std::vector<int32_t>().swap(P.fold_idx);
+    std::vector<int32_t>().swap(P.send_idx);
+    return 0;
+  }
+  // the schedule's arrays were built in place by the device builder: only the launch
+  // tables and the derived settings are left to do
+  int adopt_device_schedule() {
+    device_built = true;
+    int64_t ns = 0;
+    for (const Tile &t : P.tiles) ns += t.nslices;
+    return finish_setup(ns);
+  }
+
+  // what both builders share once the arrays are on the device: launch-slot tables, strips,
+  // kernel choice, LDS window, staging room, cache policy
+  int finish_setup(int64_t nslices_in) {
+    int rc;
+    { // per launch slot: first tile + tile range of the group that runs there
+      const int G = (int)P.group_first.size();
+      std::vector<Tile> gf(G);
+      std::vector<int2> gr(G);
+      for (int sl = 0; sl < G; sl++) {
+        const int g = (int)P.launch_order.size() == G ? P.launch_order[sl] : sl;
+        gf[sl] = P.group_first[g];
+        gr[sl] = make_int2(P.group_ptr[g], P.group_ptr[g + 1]);
+      }
+      if ((rc = gfirst.upload(gf.data(), gf.size() * sizeof(Tile)))) return rc;
+      if ((rc = group_ptr.upload(gr.data(), gr.size() * sizeof(int2)))) return rc;
+    }
     if ((rc = strip.alloc((size_t)P.nhalo * sizeof(V)))) return rc;
     halo_slots = P.nhalo;
     offblock = P.onesided_slots > 0;
@@ -1005,7 +1156,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     mirror_entries = P.mirror_entries;
     stream_len = P.stream_len;
     slot_len = P.slot_len;
-    nslices = (int64_t)P.slice_meta.size();
+    nslices = nslices_in;
     coo_len = P.coo_len;
     far_len = P.far_len;
     far_entries = P.far_entries;
@@ -1033,20 +1184,6 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     lds_bytes = (size_t)P.lds_slots * (sizeof(V) + (P.deterministic ? 16 : 8));
     // the stream is cacheable across SpMVs only if it fits the 256 MiB Infinity Cache
     nt_stream = (stream_len * (int64_t)sizeof(V) + slot_len * 2) > (int64_t)240 * 1024 * 1024;
-    // release the big host arrays; keep the small metadata
-    cfs_plan::release_async(P.vals);
-    cfs_plan::release(P.slots);
-    std::vector<uint8_t>().swap(P.leadlane);
-    std::vector<V>().swap(P.cvals);
-    std::vector<uint16_t>().swap(P.crows);
-    std::vector<uint16_t>().swap(P.ccols);
-    std::vector<V>().swap(P.fvals);
-    std::vector<uint16_t>().swap(P.frows);
-    std::vector<int32_t>().swap(P.fcols);
-    std::vector<V>().swap(P.diag);
-    std::vector<uint32_t>().swap(P.rowinfo);
-    std::vector<int32_t>().swap(P.fold_idx);
-    std::vector<int32_t>().swap(P.send_idx);
     return 0;
   }
 
@@ -1264,10 +1401,16 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   int rows() override { return P.row_end - P.row_begin; }
 };
 
+#include "cfs_devplan.hpp" // tune() on the GPU (needs SymMatrix and cfs_value_scatter_kernel)
+
 struct cfs_hip_csr_s {
   int value_bytes = 8, nrows = 0, ncols = 0, nblocks = 0;
   int64_t nnz = 0;
   DevBuf rowptr, colind, values, blk_row;
+  DevBuf chunks, longrows; // wave-stream form: chunk descriptors, rows longer than a chunk
+  int nchunks = 0, nlong = 0, wave_grid = 0, block_grid = 256 * 8;
+  bool form_measured = false; // the faster of the two kernel forms has been chosen (first SpMV)
+  bool block_form = false; // CFS_HIP_CSR_KERNEL=block: the workgroup-per-block kernel (A/B)
   HostStage stage;
   int device = 0;
 };
@@ -1300,9 +1443,13 @@ int cfs_hip_current_device(int *device) {
   if (!device) return set_err(CFS_HIP_ERR_ARG, "device is NULL");
   int rc = ensure_init();
   if (rc) return rc;
-  *device = cfs_rt::rt().home;
+  *device = cfs_rt::rt().home.load();
   return 0;
 }
+
+// 1 once a home device is bound (cfs_hip_init, or the first entry point that needed one);
+// never initialises anything itself
+int cfs_hip_runtime_bound(void) { return cfs_rt::rt().home.load() >= 0 ? 1 : 0; }
 
 int cfs_hip_default_stream(void **stream) {
   int rc = ensure_init();
@@ -1322,7 +1469,11 @@ int cfs_hip_synchronize(void *stream) {
   // a handle of this process lives on (a matrix sharded over N GPUs by the C++
   // surface runs on N of them)
   for (int d = 0; d < cfs_rt::kMaxDevices; d++) {
-    hipStream_t st = cfs_rt::rt().ctx[d].stream;
+    hipStream_t st;
+    {
+      std::lock_guard<std::mutex> lk(cfs_rt::rt().mu);
+      st = cfs_rt::rt().ctx[d].stream;
+    }
     if (!st) continue;
     DeviceGuard g(d);
     HIPCHK(hipStreamSynchronize(st));
@@ -1336,7 +1487,7 @@ int cfs_hip_alloc(size_t bytes, int kind, void **out) {
   if (rc) return rc;
   if (bytes == 0) bytes = 64;
   if (kind == CFS_HIP_MEM_DEVICE) {
-    DeviceGuard g(cfs_rt::rt().home);
+    DeviceGuard g(cfs_rt::rt().home.load());
     HIPCHK(hipMalloc(out, bytes));
   } else if (kind == CFS_HIP_MEM_PINNED) {
     return cfs_rt::pinned().alloc(bytes, out);
@@ -1348,7 +1499,13 @@ int cfs_hip_alloc(size_t bytes, int kind, void **out) {
 
 int cfs_hip_free(void *p, int kind) {
   if (!p) return 0;
-  if (kind == CFS_HIP_MEM_DEVICE) HIPCHK(hipFree(p));
+  if (kind == CFS_HIP_MEM_DEVICE) {
+    // (hipFree finds the owning device itself; the guard keeps the calling thread's
+    // current device what it was on runtimes that switch to the owner)
+    const cfs_rt::PtrInfo pi = cfs_rt::classify(p);
+    DeviceGuard g(pi.device ? pi.dev : -1);
+    HIPCHK(hipFree(p));
+  }
   else if (kind == CFS_HIP_MEM_PINNED) return cfs_rt::pinned().release(p);
   else return set_err(CFS_HIP_ERR_ARG, "unknown memory kind");
   return 0;
@@ -1377,6 +1534,12 @@ int cfs_hip_memcpy(void *dst, const void *src, size_t bytes, int dir) {
 }
 
 int cfs_hip_memset(void *dst, int value, size_t bytes) {
+  if (!dst) return set_err(CFS_HIP_ERR_ARG, "dst is NULL");
+  int rc = ensure_init();
+  if (rc) return rc;
+  const cfs_rt::PtrInfo pi = cfs_rt::classify(dst);
+  DeviceGuard g(pi.device ? pi.dev : -1);
+  if ((rc = cfs_hip_synchronize(nullptr))) return rc; // pending SpMVs on resident vectors
   HIPCHK(hipMemset(dst, value, bytes));
   return 0;
 }
@@ -1502,17 +1665,29 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   // kept until the window-shape step below has had its chance to reuse it
   cfs_plan::ScheduleSpace<V> space;
   const bool want_tuning = !(opt && (opt->flags & CFS_HIP_FLAG_NO_CALIBRATE));
-  if (!cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                               nranks > 1 ? row_splits : nullptr, po, m->P,
-                               want_tuning ? &space : nullptr)) {
-    std::string e = m->P.error;
-    delete m;
-    return set_err(plan_error_code(e), e);
-  }
-  m->nnz_caller = rowptr[n];
-  ct.lap("create: build_plan");
-  rc = m->upload();
-  ct.lap("create: upload");
+  // the schedule: built on the GPU (cfs_devplan.hpp) when the options are covered, else -- and
+  // whenever the device builder hands over -- by the host builder + upload
+  const bool host_plan = (opt && (opt->flags & CFS_HIP_FLAG_HOST_PLAN)) ||
+                         (getenv("CFS_HIP_DEVICE_PLAN") && atoi(getenv("CFS_HIP_DEVICE_PLAN")) == 0);
+  auto build_handle = [&](SymMatrix<V> *h, cfs_plan::Options &o, cfs_plan::ScheduleSpace<V> *sp) -> int {
+    h->nnz_caller = rowptr[n];
+    if (!host_plan) {
+      std::string why;
+      const int r2 = cfs_dev::build<V>(n, rowptr, colind, values, nranks, rank,
+                                       nranks > 1 ? row_splits : nullptr, o, *h, sp, why);
+      if (r2 == 0) return 0;
+      if (r2 < 0) return r2;
+      if (getenv("CFS_PLAN_VERBOSE")) fprintf(stderr, "[cfs_hip] device builder hands over: %s\n", why.c_str());
+      h->device_built = false;
+      h->plan_note = why.empty() ? "handed over" : why;
+    }
+    if (!cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank, nranks > 1 ? row_splits : nullptr, o,
+                                 h->P, sp))
+      return set_err(plan_error_code(h->P.error), h->P.error);
+    return h->upload();
+  };
+  rc = build_handle(m, po, want_tuning ? &space : nullptr);
+  ct.lap("create: schedule (build + upload)");
   if (rc) {
     delete m;
     return rc;
@@ -1584,10 +1759,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
     alt->device = cur_dev;
     alt->nnz_caller = rowptr[n];
     float t_def = 0, t_alt = 0;
-    bool ok = query_residency<V>(po2) == 0 &&
-              cfs_plan::build_plan<V>(n, rowptr, colind, values, nranks, rank,
-                                      nranks > 1 ? row_splits : nullptr, po2, alt->P, sp) &&
-              alt->upload() == 0 && choose_kernel(alt) == 0;
+    bool ok = query_residency<V>(po2) == 0 && build_handle(alt, po2, sp) == 0 && choose_kernel(alt) == 0;
     for (int round = 0; ok && round < 3; round++) {
       float a = 0, b = 0;
       ok = time_spmv(m, &a) == 0 && time_spmv(alt, &b) == 0;
@@ -1675,6 +1847,172 @@ int cfs_hip_sym_create_shard_f32(int n, const int *rowptr, const int *colind,
 
 
 // ---------------------------------------------------------------------------
+// native exchange (cfs_comm.hpp): RCCL over xGMI, or kernels / copies over peer access
+// ---------------------------------------------------------------------------
+int cfs_hip_comm_create(int ndev, const int *devices, int transport, cfs_hip_comm_t *out) {
+  if (!out || ndev < 1 || ndev > cfs_rt::kMaxDevices) return set_err(CFS_HIP_ERR_ARG, "bad argument");
+  *out = nullptr;
+  int rc = ensure_init();
+  if (rc) return rc;
+  int visible = 0, cur = 0;
+  HIPCHK(hipGetDeviceCount(&visible));
+  HIPCHK(hipGetDevice(&cur));
+  auto *c = new cfs_hip_comm_s();
+  bool distinct = true;
+  for (int g = 0; g < ndev; g++) {
+    const int d = devices ? devices[g] : (cur + g) % std::max(1, visible);
+    if (d < 0 || d >= visible) {
+      delete c;
+      return set_err(CFS_HIP_ERR_ARG, "bad device index");
+    }
+    for (int q : c->dev) distinct = distinct && q != d;
+    c->dev.push_back(d);
+  }
+  cfs_comm::Rccl &R = cfs_comm::rccl();
+  if (transport == CFS_HIP_TRANSPORT_RCCL && (!distinct || !R.ok)) {
+    const std::string why = !distinct ? "RCCL needs one rank per device" : R.why;
+    delete c;
+    return set_err(CFS_HIP_ERR_UNSUPPORTED, "rccl transport: " + why);
+  }
+  c->use_rccl = transport != CFS_HIP_TRANSPORT_PEER && distinct && R.ok;
+  if (!c->use_rccl) c->note = transport == CFS_HIP_TRANSPORT_PEER ? "asked for" : (!distinct ? "ranks share a device" : R.why);
+  if (c->use_rccl) {
+    c->comm.assign(ndev, nullptr);
+    const int r2 = R.CommInitAll(c->comm.data(), ndev, c->dev.data());
+    if (r2 != 0) {
+      const std::string e = R.GetErrorString ? R.GetErrorString(r2) : "?";
+      c->use_rccl = false; // (nothing to destroy)
+      delete c;
+      return set_err(CFS_HIP_ERR_DEVICE, "ncclCommInitAll: " + e);
+    }
+  } else {
+    c->ptrs = std::vector<DevBuf>(ndev);
+    c->ready.assign(ndev, nullptr);
+    c->done.assign(ndev, nullptr);
+    for (int g = 0; g < ndev; g++) {
+      DeviceGuard dg(c->dev[g]);
+      for (int q = 0; q < ndev; q++) // every rank reads every other rank's buffers
+        if (c->dev[q] != c->dev[g]) {
+          int can = 0;
+          (void)hipDeviceCanAccessPeer(&can, c->dev[g], c->dev[q]);
+          hipError_t e = can ? hipDeviceEnablePeerAccess(c->dev[q], 0) : hipErrorPeerAccessUnsupported;
+          if (e == hipErrorPeerAccessAlreadyEnabled) {
+            (void)hipGetLastError();
+            e = hipSuccess;
+          }
+          if (e != hipSuccess) {
+            delete c;
+            return set_err(CFS_HIP_ERR_DEVICE, "peer access between the devices of the communicator is not available");
+          }
+        }
+      if (hipEventCreateWithFlags(&c->ready[g], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&c->done[g], hipEventDisableTiming) != hipSuccess ||
+          c->ptrs[g].alloc((size_t)ndev * sizeof(void *)) != 0) {
+        delete c;
+        return set_err(CFS_HIP_ERR_DEVICE, "event / table creation failed");
+      }
+    }
+  }
+  *out = c;
+  return 0;
+}
+int cfs_hip_comm_info(cfs_hip_comm_t c, int *ndev, int *transport) {
+  if (!c) return set_err(CFS_HIP_ERR_ARG, "null communicator");
+  if (ndev) *ndev = (int)c->dev.size();
+  if (transport) *transport = c->use_rccl ? CFS_HIP_TRANSPORT_RCCL : CFS_HIP_TRANSPORT_PEER;
+  return 0;
+}
+int cfs_hip_comm_destroy(cfs_hip_comm_t c) {
+  delete c;
+  return 0;
+}
+// make `stream` (of rank `rank`) wait until the previous collective has consumed that rank's
+// send buffer (peer transport: other ranks' kernels read it; RCCL orders on the stream itself)
+int cfs_hip_comm_wait_consumed(cfs_hip_comm_t c, int rank, void *stream) {
+  if (!c || rank < 0 || rank >= (int)c->dev.size()) return set_err(CFS_HIP_ERR_ARG, "bad argument");
+  if (c->use_rccl || !c->done_valid) return 0;
+  DeviceGuard dg(c->dev[rank]);
+  for (size_t r = 0; r < c->dev.size(); r++) HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->done[r], 0));
+  return 0;
+}
+int cfs_hip_comm_reduce_scatter(cfs_hip_comm_t c, void *const *send, void *const *recv, size_t count,
+                                int value_bytes, void *const *streams) {
+  if (!c || !send || !recv || !streams || (value_bytes != 4 && value_bytes != 8))
+    return set_err(CFS_HIP_ERR_ARG, "bad argument");
+  const int N = (int)c->dev.size();
+  if (c->use_rccl) {
+    cfs_comm::Rccl &R = cfs_comm::rccl();
+    int r2 = R.GroupStart();
+    for (int g = 0; g < N && r2 == 0; g++) {
+      DeviceGuard dg(c->dev[g]);
+      r2 = R.ReduceScatter(send[g], recv[g], count, value_bytes == 8 ? cfs_comm::kNcclFloat64 : cfs_comm::kNcclFloat32,
+                           cfs_comm::kNcclSum, c->comm[g], (hipStream_t)streams[g]);
+    }
+    const int r3 = R.GroupEnd();
+    if (r2 == 0) r2 = r3;
+    if (r2 != 0) return set_err(CFS_HIP_ERR_DEVICE, std::string("ncclReduceScatter: ") + (R.GetErrorString ? R.GetErrorString(r2) : "?"));
+    return 0;
+  }
+  // peer transport: rank r sums the r-th block of every rank's send buffer
+  for (int g = 0; g < N; g++) {
+    DeviceGuard dg(c->dev[g]);
+    HIPCHK(hipEventRecord(c->ready[g], (hipStream_t)streams[g]));
+  }
+  for (int r = 0; r < N; r++) {
+    DeviceGuard dg(c->dev[r]);
+    hipStream_t st = (hipStream_t)streams[r];
+    for (int g = 0; g < N; g++) HIPCHK(hipStreamWaitEvent(st, c->ready[g], 0));
+    HIPCHK(hipMemcpyAsync(c->ptrs[r].p, send, (size_t)N * sizeof(void *), hipMemcpyHostToDevice, st));
+    const int grid = (int)std::min<size_t>((count + 255) / 256, 2048);
+    if (count) {
+      if (value_bytes == 8)
+        hipLaunchKernelGGL((cfs_comm::cfs_peer_sum_kernel<double>), dim3(grid), dim3(256), 0, st, (double *)recv[r],
+                           (const double *const *)c->ptrs[r].p, N, (size_t)r * count, count);
+      else
+        hipLaunchKernelGGL((cfs_comm::cfs_peer_sum_kernel<float>), dim3(grid), dim3(256), 0, st, (float *)recv[r],
+                           (const float *const *)c->ptrs[r].p, N, (size_t)r * count, count);
+    }
+    HIPCHK(hipEventRecord(c->done[r], st));
+  }
+  c->done_valid = true;
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+int cfs_hip_comm_allgather(cfs_hip_comm_t c, void *const *send, void *const *recv, size_t count,
+                           int value_bytes, void *const *streams) {
+  if (!c || !send || !recv || !streams || (value_bytes != 4 && value_bytes != 8))
+    return set_err(CFS_HIP_ERR_ARG, "bad argument");
+  const int N = (int)c->dev.size();
+  if (c->use_rccl) {
+    cfs_comm::Rccl &R = cfs_comm::rccl();
+    int r2 = R.GroupStart();
+    for (int g = 0; g < N && r2 == 0; g++) {
+      DeviceGuard dg(c->dev[g]);
+      r2 = R.AllGather(send[g], recv[g], count, value_bytes == 8 ? cfs_comm::kNcclFloat64 : cfs_comm::kNcclFloat32,
+                       c->comm[g], (hipStream_t)streams[g]);
+    }
+    const int r3 = R.GroupEnd();
+    if (r2 == 0) r2 = r3;
+    if (r2 != 0) return set_err(CFS_HIP_ERR_DEVICE, std::string("ncclAllGather: ") + (R.GetErrorString ? R.GetErrorString(r2) : "?"));
+    return 0;
+  }
+  // peer transport: rank g pushes its block into every rank's receive buffer
+  const size_t bytes = count * (size_t)value_bytes;
+  for (int g = 0; g < N; g++) {
+    DeviceGuard dg(c->dev[g]);
+    hipStream_t st = (hipStream_t)streams[g];
+    for (int r = 0; r < N && bytes; r++)
+      HIPCHK(hipMemcpyPeerAsync((char *)recv[r] + (size_t)g * bytes, c->dev[r], send[g], c->dev[g], bytes, st));
+    HIPCHK(hipEventRecord(c->ready[g], st));
+  }
+  for (int r = 0; r < N; r++) {
+    DeviceGuard dg(c->dev[r]);
+    for (int g = 0; g < N; g++) HIPCHK(hipStreamWaitEvent((hipStream_t)streams[r], c->ready[g], 0));
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
 // One host thread, N GPUs (the C++ surface with CFS_NUM_GPUS=N; reference knob:
 // CFS_NUM_THREADS, src/runtime.cpp:10-21): N mirrored 1-D row-block shards, one per
 // device, each on a stream of its own.  x and y stay where the caller put them (the
@@ -1692,6 +2030,118 @@ struct MultiSym : cfs_hip_sym_s {
   hipEvent_t start_ = nullptr;
   int n_ = 0;
   std::vector<int32_t> none_;
+  // How a shard on another device than the handle's home reaches x and y:
+  //   CFS_HIP_XMODE_REPLICATE (default)  x is REPLICATED (north-star / SURVEY 8e): one
+  //       hipMemcpyPeerAsync home -> device per shard and SpMV into the shard's own copy,
+  //       the kernels gather x and write their y block in LOCAL HBM, one peer copy brings
+  //       the block home;
+  //   CFS_HIP_XMODE_PEER  the kernels read x and write y in the home device's memory
+  //       through peer access over xGMI (no copies, every gather crosses the fabric).
+  // Shards on the home device itself never copy.  CFS_HIP_XMODE_REPLICATE_ALL copies for
+  // every shard, home or not: the way a one-GPU box exercises the copy path.
+  int xmode = CFS_HIP_XMODE_REPLICATE;
+  std::vector<DevBuf> xrep, yloc; // per shard, on its device (allocated on first use)
+  int ensure_copies(size_t g) {
+    if (xrep.size() != shard.size()) {
+      xrep = std::vector<DevBuf>(shard.size());
+      yloc = std::vector<DevBuf>(shard.size());
+    }
+    if (xrep[g].p) return 0;
+    DeviceGuard dg(dev[g]);
+    int rc;
+    if ((rc = xrep[g].alloc((size_t)n_ * value_bytes))) return rc;
+    return yloc[g].alloc((size_t)(splits[g + 1] - splits[g]) * value_bytes);
+  }
+  bool copies(size_t g) const {
+    return xmode == CFS_HIP_XMODE_REPLICATE_ALL || (xmode == CFS_HIP_XMODE_REPLICATE && dev[g] != device);
+  }
+  // Exchange form (CFS_HIP_FLAG_SHARD_EXCHANGE at create, or CFS_MULTI_EXCHANGE=reduce_scatter):
+  // the shards keep their off-block entries two-sided, pack the contributions to rows of lower
+  // ranks, scatter them into a dense vector of N equal blocks and ONE native reduce-scatter
+  // (cfs_hip_comm_*: RCCL over xGMI, or the peer transport) hands every owner its sums --
+  // the north-star's form, without Python.  The local fold runs beside the collective.
+  cfs_hip_comm_s *comm = nullptr;
+  int rs_rows = 0; // block length of the reduce-scatter (longest row block)
+  std::vector<DevBuf> sbuf, pos, dense, rsout;
+  std::vector<int> nsend_;
+  template <typename V> int setup_exchange(int transport) {
+    const int N = (int)shard.size();
+    int rc = cfs_hip_comm_create(N, dev.data(), transport, &comm);
+    if (rc) return rc;
+    rs_rows = 0;
+    for (int g = 0; g < N; g++) rs_rows = std::max(rs_rows, splits[g + 1] - splits[g]);
+    sbuf = std::vector<DevBuf>(N);
+    pos = std::vector<DevBuf>(N);
+    dense = std::vector<DevBuf>(N);
+    rsout = std::vector<DevBuf>(N);
+    nsend_.assign(N, 0);
+    for (int g = 0; g < N; g++) {
+      DeviceGuard dg(dev[g]);
+      const std::vector<int32_t> &rows = shard[g]->send_rows();
+      nsend_[g] = (int)rows.size();
+      std::vector<int32_t> p(rows.size());
+      for (size_t k = 0; k < rows.size(); k++) {
+        const int owner = (int)(std::upper_bound(splits.begin(), splits.end(), rows[k]) - splits.begin()) - 1;
+        p[k] = owner * rs_rows + (rows[k] - splits[owner]);
+      }
+      if ((rc = pos[g].upload(p.data(), p.size() * 4)) || (rc = sbuf[g].alloc(std::max<size_t>(1, rows.size()) * sizeof(V))) ||
+          (rc = dense[g].alloc((size_t)N * rs_rows * sizeof(V))) || (rc = rsout[g].alloc((size_t)rs_rows * sizeof(V))))
+        return rc;
+      // this shard receives nothing through the sparse route: recv side stays empty
+    }
+    return 0;
+  }
+  template <typename V> int spmv_exchange(void *y, const void *x, hipStream_t st) {
+    const int N = (int)shard.size();
+    HIPCHK(hipEventRecord(start_, st));
+    std::vector<void *> sp(N), rp(N), streams(N);
+    std::vector<const void *> xg(N);
+    std::vector<void *> yg(N);
+    for (int g = 0; g < N; g++) {
+      DeviceGuard dg(dev[g]);
+      HIPCHK(hipStreamWaitEvent(st_[g], start_, 0));
+      int rc;
+      xg[g] = x;
+      yg[g] = (char *)y + (size_t)splits[g] * value_bytes;
+      if (copies(g)) {
+        if ((rc = ensure_copies(g))) return rc;
+        HIPCHK(hipMemcpyPeerAsync(xrep[g].p, dev[g], x, device, (size_t)n_ * value_bytes, st_[g]));
+        xg[g] = xrep[g].p;
+        yg[g] = yloc[g].p;
+      }
+      if ((rc = cfs_hip_comm_wait_consumed(comm, g, st_[g]))) return rc;
+      HIPCHK(hipMemsetAsync(dense[g].p, 0, (size_t)N * rs_rows * sizeof(V), st_[g]));
+      rc = shard[g]->spmv_local(yg[g], xg[g], sbuf[g].p, st_[g], CFS_HIP_PHASE_TILES | CFS_HIP_PHASE_PACK);
+      if (rc) return rc;
+      if (nsend_[g] > 0)
+        hipLaunchKernelGGL((cfs_scatter_pos_kernel<V>), dim3((nsend_[g] + 255) / 256), dim3(256), 0, st_[g],
+                           (V *)dense[g].p, (const int32_t *)pos[g].p, (const V *)sbuf[g].p, nsend_[g]);
+      sp[g] = dense[g].p;
+      rp[g] = rsout[g].p;
+      streams[g] = (void *)st_[g];
+    }
+    int rc = cfs_hip_comm_reduce_scatter(comm, sp.data(), rp.data(), (size_t)rs_rows, value_bytes, streams.data());
+    if (rc) return rc;
+    for (int g = 0; g < N; g++) {
+      DeviceGuard dg(dev[g]);
+      const int rows_g = splits[g + 1] - splits[g];
+      // (stream order: the local fold is enqueued behind the collective of this rank; on the
+      // RCCL transport the two run on the same stream, on the peer transport the sum kernel is
+      // short -- overlapping them needs a second stream per shard and has not been measured)
+      rc = shard[g]->spmv_local(yg[g], xg[g], sbuf[g].p, st_[g], CFS_HIP_PHASE_FOLD);
+      if (rc) return rc;
+      if (rows_g > 0)
+        hipLaunchKernelGGL((cfs_add_rows_kernel<V>), dim3((rows_g + 255) / 256), dim3(256), 0, st_[g], (V *)yg[g],
+                           (const V *)rsout[g].p, rows_g);
+      if (copies(g) && rows_g > 0)
+        HIPCHK(hipMemcpyPeerAsync((char *)y + (size_t)splits[g] * value_bytes, device, yloc[g].p, dev[g],
+                                  (size_t)rows_g * value_bytes, st_[g]));
+      HIPCHK(hipEventRecord(done_[g], st_[g]));
+    }
+    for (int g = 0; g < N; g++) HIPCHK(hipStreamWaitEvent(st, done_[g], 0));
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
   ~MultiSym() override {
     for (size_t g = 0; g < shard.size(); g++) {
       DeviceGuard dg(dev[g]);
@@ -1704,15 +2154,28 @@ struct MultiSym : cfs_hip_sym_s {
       DeviceGuard dg(device);
       (void)hipEventDestroy(start_);
     }
+    delete comm;
   }
   int spmv_local(void *y, const void *x, void *, hipStream_t st, int phases) override {
+    if (comm) return value_bytes == 8 ? spmv_exchange<double>(y, x, st) : spmv_exchange<float>(y, x, st);
     HIPCHK(hipEventRecord(start_, st));
     for (size_t g = 0; g < shard.size(); g++) {
       DeviceGuard dg(dev[g]);
       HIPCHK(hipStreamWaitEvent(st_[g], start_, 0));
-      int rc = shard[g]->spmv_local((char *)y + (size_t)splits[g] * value_bytes, x, nullptr, st_[g],
-                                    phases & (CFS_HIP_PHASE_TILES | CFS_HIP_PHASE_FOLD));
-      if (rc) return rc;
+      char *yg = (char *)y + (size_t)splits[g] * value_bytes;
+      const size_t ybytes = (size_t)(splits[g + 1] - splits[g]) * value_bytes;
+      int rc;
+      if (copies(g)) { // replicated x, local y block
+        if ((rc = ensure_copies(g))) return rc;
+        HIPCHK(hipMemcpyPeerAsync(xrep[g].p, dev[g], x, device, (size_t)n_ * value_bytes, st_[g]));
+        rc = shard[g]->spmv_local(yloc[g].p, xrep[g].p, nullptr, st_[g],
+                                  phases & (CFS_HIP_PHASE_TILES | CFS_HIP_PHASE_FOLD));
+        if (rc) return rc;
+        if (ybytes) HIPCHK(hipMemcpyPeerAsync(yg, device, yloc[g].p, dev[g], ybytes, st_[g]));
+      } else {
+        rc = shard[g]->spmv_local(yg, x, nullptr, st_[g], phases & (CFS_HIP_PHASE_TILES | CFS_HIP_PHASE_FOLD));
+        if (rc) return rc;
+      }
       HIPCHK(hipEventRecord(done_[g], st_[g]));
     }
     for (size_t g = 0; g < shard.size(); g++) HIPCHK(hipStreamWaitEvent(st, done_[g], 0));
@@ -1789,6 +2252,9 @@ static int sym_create_multi(int n, const int *rowptr, const int *colind, const V
   m->n_ = n;
   m->splits.assign(ngpus + 1, 0);
   cfs_plan::balanced_splits(n, rowptr, colind, ngpus, m->splits.data());
+  if (const char *e = getenv("CFS_MULTI_X")) // peer | replicate | replicate_all
+    m->xmode = !strcmp(e, "peer") ? CFS_HIP_XMODE_PEER
+               : !strcmp(e, "replicate_all") ? CFS_HIP_XMODE_REPLICATE_ALL : CFS_HIP_XMODE_REPLICATE;
   {
     DeviceGuard dg(home);
     if (hipEventCreateWithFlags(&m->start_, hipEventDisableTiming) != hipSuccess) {
@@ -1799,7 +2265,14 @@ static int sym_create_multi(int n, const int *rowptr, const int *colind, const V
   cfs_hip_options o2;
   memset(&o2, 0, sizeof o2);
   if (opt) o2 = *opt;
-  o2.flags &= ~CFS_HIP_FLAG_SHARD_EXCHANGE; // one process: mirrored shards, nothing to exchange
+  // default: mirrored shards, nothing to exchange.  With CFS_HIP_FLAG_SHARD_EXCHANGE (or
+  // CFS_MULTI_EXCHANGE=reduce_scatter) the shards take the exchange form and one native
+  // reduce-scatter per SpMV (MultiSym::spmv_exchange)
+  bool exchange = (o2.flags & CFS_HIP_FLAG_SHARD_EXCHANGE) != 0;
+  if (const char *e = getenv("CFS_MULTI_EXCHANGE")) exchange = !strcmp(e, "reduce_scatter");
+  if (ngpus < 2) exchange = false;
+  if (exchange) o2.flags = (o2.flags | CFS_HIP_FLAG_SHARD_EXCHANGE) & ~(CFS_HIP_FLAG_HYB);
+  else o2.flags &= ~CFS_HIP_FLAG_SHARD_EXCHANGE;
   for (int g = 0; g < ngpus; g++) {
     // devices[g] when given, else the visible devices round-robin (several shards may
     // share a device: that is how a one-GPU box rehearses the path)
@@ -1843,6 +2316,16 @@ static int sym_create_multi(int n, const int *rowptr, const int *colind, const V
     }
     m->shard.push_back(h);
   }
+  if (exchange) {
+    int transport = CFS_HIP_TRANSPORT_AUTO;
+    if (const char *e = getenv("CFS_MULTI_TRANSPORT"))
+      transport = !strcmp(e, "rccl") ? CFS_HIP_TRANSPORT_RCCL : (!strcmp(e, "peer") ? CFS_HIP_TRANSPORT_PEER : CFS_HIP_TRANSPORT_AUTO);
+    if ((rc = m->template setup_exchange<V>(transport))) {
+      std::string e = cfs_rt::last_error();
+      delete m;
+      return set_err(rc, e);
+    }
+  }
   *out = m;
   return 0;
 }
@@ -1855,6 +2338,30 @@ int cfs_hip_sym_create_multi_f32(int n, const int *rowptr, const int *colind, co
                                  int ngpus, const int *devices, const cfs_hip_options *opt,
                                  cfs_hip_sym_t *out) {
   return sym_create_multi<float>(n, rowptr, colind, values, ngpus, devices, opt, out);
+}
+int cfs_hip_sym_multi_set_xmode(cfs_hip_sym_t h, int xmode) {
+  auto *m = dynamic_cast<MultiSym *>(h);
+  if (!m) return set_err(CFS_HIP_ERR_ARG, "not a multi-device handle");
+  if (xmode != CFS_HIP_XMODE_PEER && xmode != CFS_HIP_XMODE_REPLICATE && xmode != CFS_HIP_XMODE_REPLICATE_ALL)
+    return set_err(CFS_HIP_ERR_ARG, "unknown x mode");
+  // pending SpMVs of the other mode finish first
+  for (size_t g = 0; g < m->shard.size(); g++) {
+    DeviceGuard dg(m->dev[g]);
+    HIPCHK(hipStreamSynchronize(m->st_[g]));
+  }
+  m->xmode = xmode;
+  return 0;
+}
+int cfs_hip_sym_multi_devices(cfs_hip_sym_t h, int *devices, int capacity, int *distinct) {
+  auto *m = dynamic_cast<MultiSym *>(h);
+  if (!m || !distinct) return set_err(CFS_HIP_ERR_ARG, "not a multi-device handle");
+  std::vector<int> seen;
+  for (size_t g = 0; g < m->dev.size(); g++) {
+    if (devices && (int)g < capacity) devices[g] = m->dev[g];
+    if (std::find(seen.begin(), seen.end(), m->dev[g]) == seen.end()) seen.push_back(m->dev[g]);
+  }
+  *distinct = (int)seen.size();
+  return 0;
 }
 int cfs_hip_sym_num_gpus(cfs_hip_sym_t h, int *ngpus) {
   if (!h || !ngpus) return set_err(CFS_HIP_ERR_ARG, "null argument");
@@ -2000,6 +2507,72 @@ int cfs_hip_sym_get_stats(cfs_hip_sym_t h, cfs_hip_sym_stats *out) {
   if (!h || !out) return set_err(CFS_HIP_ERR_ARG, "null argument");
   h->stats(out);
   return 0;
+}
+
+// developer / test: digests of the schedule's device arrays (cfs_hip.h)
+static unsigned long long fnv1a(const void *p, size_t n, unsigned long long h = 1469598103934665603ull) {
+  const unsigned char *b = (const unsigned char *)p;
+  for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+template <typename V> static int sym_digest(SymMatrix<V> *m, unsigned long long *w) {
+  DeviceGuard g(m->device);
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<unsigned char> buf;
+  auto dig = [&](const DevBuf &b, size_t bytes, unsigned long long *out) -> int {
+    *out = 0;
+    if (!b.p || bytes == 0) return 0;
+    buf.resize(bytes);
+    HIPCHK(hipMemcpy(buf.data(), b.p, bytes, hipMemcpyDeviceToHost));
+    *out = fnv1a(buf.data(), bytes);
+    return 0;
+  };
+  const SymPlan<V> &P = m->P;
+  const size_t T = P.tiles.size(), G = P.group_first.size(), s = sizeof(V);
+  int64_t nsl = 0, nvr = 0;
+  for (const Tile &t : P.tiles) nsl += t.nslots, nvr += t.nvrows;
+  int rc, k = 0;
+  { // tiles, aexp masked (the device builder does not compute it: the deterministic build only)
+    std::vector<Tile> tt(T);
+    if (T) HIPCHK(hipMemcpy(tt.data(), m->tiles.p, T * sizeof(Tile), hipMemcpyDeviceToHost));
+    for (auto &t : tt) t.aexp = 0;
+    w[k++] = fnv1a(tt.data(), T * sizeof(Tile));
+    std::vector<Tile> gf(G);
+    if (G) HIPCHK(hipMemcpy(gf.data(), m->gfirst.p, G * sizeof(Tile), hipMemcpyDeviceToHost));
+    for (auto &t : gf) t.aexp = 0;
+    w[k++] = fnv1a(gf.data(), G * sizeof(Tile));
+  }
+  if ((rc = dig(m->group_ptr, G * sizeof(int2), &w[k++]))) return rc;
+  if ((rc = dig(m->slot_col, (size_t)nsl * 4, &w[k++]))) return rc;
+  if ((rc = dig(m->rowinfo, (size_t)nvr * 4, &w[k++]))) return rc;
+  if ((rc = dig(m->diag, (size_t)nvr * s, &w[k++]))) return rc;
+  if ((rc = dig(m->slice_meta, (size_t)m->nslices * 16, &w[k++]))) return rc;
+  if ((rc = dig(m->leadlane, (size_t)m->nslices * 64, &w[k++]))) return rc;
+  if ((rc = dig(m->vals, (size_t)m->stream_len * s, &w[k++]))) return rc;
+  if ((rc = dig(m->slots, (size_t)m->slot_len * 2, &w[k++]))) return rc;
+  if ((rc = dig(m->cvals, (size_t)m->coo_len * s, &w[k++]))) return rc;
+  if ((rc = dig(m->crows, (size_t)m->coo_len * 2, &w[k++]))) return rc;
+  if ((rc = dig(m->ccols, (size_t)m->coo_len * 2, &w[k++]))) return rc;
+  if ((rc = dig(m->fold_rec, (size_t)(m->nfold + 1) * sizeof(int4), &w[k++]))) return rc;
+  if ((rc = dig(m->fold_idx, m->fold_idx.bytes, &w[k++]))) return rc;
+  if ((rc = dig(m->val_map, m->has_value_map ? (size_t)m->stream_len * 4 : 0, &w[k++]))) return rc;
+  if ((rc = dig(m->cval_map, m->has_value_map ? (size_t)m->coo_len * 4 : 0, &w[k++]))) return rc;
+  if ((rc = dig(m->diag_map, m->has_value_map ? (size_t)nvr * 4 : 0, &w[k++]))) return rc;
+  w[k++] = (unsigned long long)m->P.lds_slots | ((unsigned long long)m->P.ngroups << 32);
+  w[CFS_HIP_DIGEST_WORDS - 1] = m->device_built ? 1ull : 0ull;
+  return 0;
+}
+int cfs_hip_sym_debug_plan_note(cfs_hip_sym_t h, char *buf, int capacity) {
+  if (!h || !buf || capacity < 1) return set_err(CFS_HIP_ERR_ARG, "bad argument");
+  snprintf(buf, (size_t)capacity, "%s", h->plan_note.c_str());
+  return 0;
+}
+int cfs_hip_sym_debug_digest(cfs_hip_sym_t h, unsigned long long *words, int capacity_words) {
+  if (!h || !words || capacity_words < CFS_HIP_DIGEST_WORDS) return set_err(CFS_HIP_ERR_ARG, "bad argument");
+  for (int i = 0; i < CFS_HIP_DIGEST_WORDS; i++) words[i] = 0;
+  if (auto *d = dynamic_cast<SymMatrix<double> *>(h)) return sym_digest<double>(d, words);
+  if (auto *f = dynamic_cast<SymMatrix<float> *>(h)) return sym_digest<float>(f, words);
+  return set_err(CFS_HIP_ERR_ARG, "no digest for a multi-device handle");
 }
 
 // ---- host-only plan self-check (no device needed) -------------------------
@@ -2245,9 +2818,11 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
   if (!out || !rowptr || nrows < 0) return set_err(CFS_HIP_ERR_ARG, "bad argument");
   int rc = ensure_init();
   if (rc) return rc;
+  int cur_dev = 0;
+  HIPCHK(hipGetDevice(&cur_dev));
   auto *m = new cfs_hip_csr_s();
   m->value_bytes = (int)sizeof(V);
-  HIPCHK(hipGetDevice(&m->device));
+  m->device = cur_dev;
   m->nrows = nrows;
   m->ncols = ncols;
   m->nnz = rowptr[nrows];
@@ -2273,6 +2848,41 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
       return rc;
     }
   }
+  { // wave-stream form: chunks of whole rows (<= kCwNnz nonzeros, <= kCwRows rows); longer rows apart
+    std::vector<int4> cd;
+    std::vector<int32_t> lr;
+    int r = 0;
+    while (r < nrows) {
+      if (rowptr[r + 1] - rowptr[r] > kCwNnz) {
+        lr.push_back(r++);
+        continue;
+      }
+      int e = r;
+      while (e < nrows && e - r < kCwRows && rowptr[e + 1] - rowptr[r] <= kCwNnz) e++;
+      cd.push_back(make_int4(r, e - r, rowptr[r], rowptr[e] - rowptr[r]));
+      r = e;
+    }
+    m->nchunks = (int)cd.size();
+    m->nlong = (int)lr.size();
+    if ((rc = m->chunks.upload(cd.data(), cd.size() * sizeof(int4))) ||
+        (rc = m->longrows.upload(lr.data(), lr.size() * 4))) {
+      delete m;
+      return rc;
+    }
+    // persistent waves: as many workgroups as are co-resident
+    int nb = 0;
+    const void *k = sizeof(V) == 8 ? (const void *)cfs_csr_wave_kernel<double> : (const void *)cfs_csr_wave_kernel<float>;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, 0) != hipSuccess || nb < 1) nb = 4;
+    if (hipGetDeviceProperties(&prop, m->device) != hipSuccess) prop.multiProcessorCount = 256;
+    m->wave_grid = std::max(1, std::min((m->nchunks + 3) / 4, prop.multiProcessorCount * nb));
+    m->block_form = true;
+    m->form_measured = false;
+    if (const char *e = getenv("CFS_HIP_CSR_KERNEL")) { // block | wave: no measurement
+      m->block_form = strcmp(e, "wave") != 0;
+      m->form_measured = true;
+    }
+  }
   *out = m;
   return 0;
 }
@@ -2285,11 +2895,62 @@ int cfs_hip_csr_create_f32(int nrows, int ncols, const int *rowptr, const int *c
   return csr_create<float>(nrows, ncols, rowptr, colind, values, out);
 }
 
+static int csr_launch(cfs_hip_csr_t h, void *y, const void *x, hipStream_t st);
+// the faster of the two kernel forms, measured once with the caller's own vectors (y is fully
+// overwritten by either): five SpMVs each after one warm-up, on the caller's stream
+static int csr_choose_form(cfs_hip_csr_t h, void *y, const void *x, hipStream_t st) {
+  h->form_measured = true;
+  if (h->nnz < (int64_t)1 << 20) return 0; // small: the block form
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0;
+  float t[2] = {0, 0};
+  for (int form = 0; form < 2; form++) {
+    h->block_form = form == 0;
+    int rc = csr_launch(h, y, x, st);
+    (void)hipEventRecord(a, st);
+    for (int it = 0; it < 5 && !rc; it++) rc = csr_launch(h, y, x, st);
+    (void)hipEventRecord(b, st);
+    if (rc || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&t[form], a, b) != hipSuccess) t[form] = 1e30f;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  h->block_form = t[0] <= t[1];
+  if (getenv("CFS_PLAN_VERBOSE"))
+    fprintf(stderr, "[cfs_hip] general CSR kernel: block form %.1f us, wave form %.1f us\n", t[0] * 200.0, t[1] * 200.0);
+  return 0;
+}
 int cfs_hip_csr_spmv_async(cfs_hip_csr_t h, void *y, const void *x, void *stream) {
   if (!h || !y || !x) return set_err(CFS_HIP_ERR_ARG, "null argument");
-  hipStream_t st = (hipStream_t)stream;
   DeviceGuard g(h->device);
-  if (h->nblocks > 0) {
+  if (!h->form_measured) {
+    int rc = csr_choose_form(h, y, x, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return csr_launch(h, y, x, (hipStream_t)stream);
+}
+static int csr_launch(cfs_hip_csr_t h, void *y, const void *x, hipStream_t st) {
+  if (!h->block_form) {
+    if (h->nchunks > 0) {
+      if (h->value_bytes == 8)
+        hipLaunchKernelGGL((cfs_csr_wave_kernel<double>), dim3(h->wave_grid), dim3(256), 0, st,
+                           (const int4 *)h->chunks.p, h->nchunks, (const int32_t *)h->rowptr.p,
+                           (const int32_t *)h->colind.p, (const double *)h->values.p, (const double *)x, (double *)y);
+      else
+        hipLaunchKernelGGL((cfs_csr_wave_kernel<float>), dim3(h->wave_grid), dim3(256), 0, st,
+                           (const int4 *)h->chunks.p, h->nchunks, (const int32_t *)h->rowptr.p,
+                           (const int32_t *)h->colind.p, (const float *)h->values.p, (const float *)x, (float *)y);
+    }
+    if (h->nlong > 0) {
+      if (h->value_bytes == 8)
+        hipLaunchKernelGGL((cfs_csr_longrow_kernel<double>), dim3(h->nlong), dim3(256), 0, st,
+                           (const int32_t *)h->longrows.p, (const int32_t *)h->rowptr.p, (const int32_t *)h->colind.p,
+                           (const double *)h->values.p, (const double *)x, (double *)y);
+      else
+        hipLaunchKernelGGL((cfs_csr_longrow_kernel<float>), dim3(h->nlong), dim3(256), 0, st,
+                           (const int32_t *)h->longrows.p, (const int32_t *)h->rowptr.p, (const int32_t *)h->colind.p,
+                           (const float *)h->values.p, (const float *)x, (float *)y);
+    }
+  } else if (h->nblocks > 0) {
     const int grid = h->nblocks < 256 * 8 ? h->nblocks : 256 * 8;
     if (h->value_bytes == 8)
       hipLaunchKernelGGL((cfs_csr_stream_kernel<double>), dim3(grid), dim3(256), 0, st,
@@ -2303,6 +2964,13 @@ int cfs_hip_csr_spmv_async(cfs_hip_csr_t h, void *y, const void *x, void *stream
                          (const float *)x, (float *)y);
   }
   HIPCHK(hipGetLastError());
+  return 0;
+}
+
+int cfs_hip_csr_kernel_form(cfs_hip_csr_t h, int *form, int *measured) {
+  if (!h || !form) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  *form = h->block_form ? CFS_HIP_CSR_FORM_BLOCK : CFS_HIP_CSR_FORM_WAVE;
+  if (measured) *measured = h->form_measured ? 1 : 0;
   return 0;
 }
 

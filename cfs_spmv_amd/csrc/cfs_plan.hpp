@@ -133,7 +133,9 @@ constexpr int kAlignEntries = 8;      // slice streams start on 8-entry bounds
 constexpr int kDefaultSlots = 4992;    // 2 workgroups x (4992 x 16 B + 16 B) fit the 160 KiB of a CU
 constexpr int kDefaultBlock = 512;    // 8 waves per workgroup, 16 per CU (measured best)
 constexpr int kStaticLds = 16;        // slice ticket counter
+constexpr int kAexpNonFinite = 30000; // Tile::aexp of a tile that holds a NaN / Inf value
 constexpr int kSlotsPerThread = 10;   // LDS slots one thread fills/flushes (registers)
+constexpr int kStreamPad = 256;       // padding entries behind the value / slot streams (one packet)
 
 // Threads for the host-side schedule build: the OpenMP default, capped by the
 // affinity mask and by the cgroup CPU quota (a container that shows 256 cores but
@@ -210,6 +212,7 @@ template <typename V> struct SymPlan {
   int64_t nnz_low = 0, nnz_diag = 0, nnz_full = 0;
   // knobs actually used
   int max_slots = 0, block_threads = 0, lds_slots = 0;
+  int wg_per_cu = 1; // co-resident workgroups per CU the persistent grid was sized for
   bool deterministic = false;
   // launch shape: `ngroups` persistent workgroups (a multiple of 8); workgroup b runs
   // group (b % 8) * (ngroups / 8) + b / 8
@@ -394,6 +397,43 @@ template <typename V> inline ChunkLayout chunk_layout(int rows, const Options &o
   return L;
 }
 
+// Which workgroup runs which group.  With two workgroups per CU the dispatcher
+// places workgroups 0 .. G/2-1 first (one per CU) and G/2 .. G-1 as the second
+// workgroup of the same CUs: those start 2 us later and -- the older workgroup of a
+// CU wins its arbitration -- end 5 us later (tools/calib_probe.py).  The expensive
+// groups of an XCD's run (several tiles, ragged clusters with much halo: the last
+// clusters of every clustering sweep) therefore go FIRST, and the second workgroup
+// of a CU is the cheapest partner for its first: longest-processing-time pairing
+// on the model cost of a group.  Same XCD, same L2 as before.
+// (cost: [rows + 1] prefix of the row costs, local row index = row - rb)
+inline void compute_launch_order(const ChunkLayout &L, const Options &opt, const std::vector<Tile> &tiles,
+                                 const std::vector<int32_t> &group_ptr, const std::vector<int64_t> &cost,
+                                 int rb, std::vector<int32_t> &launch_order) {
+  const int nc = L.nchunks();
+  launch_order.resize(nc);
+  for (int g = 0; g < nc; g++) launch_order[g] = g;
+  if (opt.cost_model && L.full_grid && L.wg_per_cu == 2 && nc % 16 == 0 && env_or("CFS_HIP_LAUNCH_ORDER", 1) != 0) {
+    const ClusterCost cm = L.cluster_cost(opt);
+    std::vector<double> gc(nc, 0.0);
+    for (int g = 0; g < nc; g++) {
+      const int t0 = group_ptr[g], t1 = group_ptr[g + 1];
+      for (int ti = t0; ti < t1; ti++) gc[g] += (double)(tiles[ti].nslots - tiles[ti].nown) * cm.per_halo;
+      gc[g] += (double)std::max(0, t1 - t0 - 1) * cm.per_tile;
+      if (t1 > t0) gc[g] += (double)(cost[tiles[t1 - 1].row0 + tiles[t1 - 1].nown - rb] - cost[tiles[t0].row0 - rb]);
+    }
+    const int nper = nc / 8, h = nper / 2;
+    std::vector<int32_t> idx(nper);
+    for (int x = 0; x < 8; x++) {
+      for (int k = 0; k < nper; k++) idx[k] = x * nper + k;
+      std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return gc[a] > gc[b]; });
+      for (int j = 0; j < h; j++) {
+        launch_order[x * nper + j] = idx[j];                // first wave: heaviest first
+        launch_order[x * nper + h + j] = idx[nper - 1 - j]; // its CU partner: lightest
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------
 // The builder: the phases of one schedule build, in the order they run
 //   count_rows   stored (near) entries per row, cost prefix
@@ -511,6 +551,7 @@ template <typename V> struct Builder {
       }
     }
     P.block_threads = L.block;
+    P.wg_per_cu = L.wg_per_cu;
     P.max_slots = L.max_slots;
     P.ngroups = L.ngroups;
     P.deterministic = opt.deterministic;
@@ -997,8 +1038,8 @@ template <typename V> struct Builder {
     P.coo_len = coo;
     // one packet of padding: the kernel prefetches a slice's first packet with
     // every lane before it knows how many lanes the packet really has
-    par_assign(P.vals, (size_t)off + 256, V(0)); // zeros: the padding of the packets
-    par_assign(P.slots, (size_t)soff + 256, (uint16_t)0);
+    par_assign(P.vals, (size_t)off + kStreamPad, V(0)); // zeros: the padding of the packets
+    par_assign(P.slots, (size_t)soff + kStreamPad, (uint16_t)0);
     P.cvals.assign((size_t)coo + 256, V(0));
     P.crows.assign((size_t)coo + 256, 0);
     P.ccols.assign((size_t)coo + 256, 0);
@@ -1006,7 +1047,7 @@ template <typename V> struct Builder {
     P.frows.assign((size_t)P.far_len + 256, 0);
     P.fcols.assign((size_t)P.far_len + 256, 0);
     if (opt.keep_value_map) {
-      par_assign(P.val_map, (size_t)off + 256, (int32_t)-1);
+      par_assign(P.val_map, (size_t)off + kStreamPad, (int32_t)-1);
       P.cval_map.assign((size_t)coo + 256, -1);
       P.fval_map.assign((size_t)P.far_len + 256, -1);
       P.diag_map.assign((size_t)nvr + 1, -1);
@@ -1094,6 +1135,7 @@ template <typename V> struct Builder {
         uint16_t *ts = P.slots.data() + t.sl_off;
         std::vector<std::vector<int32_t>> low(kLanes);
         double amax_t = 0.0; // largest |value| of the tile
+        int nonfinite_t = 0;  // ... and whether a NaN / Inf is among its values
         for (int s = 0; s < t.nslices && !bad; s++) {
           int p0 = s * kLanes, m = std::min(kLanes, (int)t.nvrows - p0);
           int amax = 0;
@@ -1114,6 +1156,7 @@ template <typename V> struct Builder {
             P.diag[t.vrow_off + p0 + l] = d;
             if (keep && dj >= 0) P.diag_map[t.vrow_off + p0 + l] = srcpos ? srcpos[dj] : dj;
             amax_t = std::max(amax_t, std::fabs((double)d));
+            nonfinite_t |= !std::isfinite((double)d);
           }
           const SliceMeta &sm = P.slice_meta[t.slice_base + s];
           int64_t o = sm.voff, os = sm.soff_cnt0 & 0x1ffffff;
@@ -1132,6 +1175,7 @@ template <typename V> struct Builder {
                 if (keep)
                   P.val_map[t.nnz_off + o + packet_val_pos<V>(l, j, cnt)] = src_at(t.row0 + vr[p0 + l].r, q);
                 amax_t = std::max(amax_t, std::fabs((double)av));
+                nonfinite_t |= !std::isfinite((double)av);
                 if (is_leader) ts[os + packet_slot_pos(lead, j)] = slot_of(colind[q]);
               }
             }
@@ -1156,6 +1200,7 @@ template <typename V> struct Builder {
               cv[pk * 256 + packet_val_pos<V>(l, j)] = av;
               if (keep) P.cval_map[t.coo_off + pk * 256 + packet_val_pos<V>(l, j)] = src_at(t.row0 + r, q);
               amax_t = std::max(amax_t, std::fabs((double)av));
+              nonfinite_t |= !std::isfinite((double)av);
               cr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)r;
               cc[pk * 256 + packet_slot_pos(l, j)] = slot_of(colind[q]);
               e++;
@@ -1188,11 +1233,14 @@ template <typename V> struct Builder {
             fv[pk * 256 + packet_val_pos<V>(l, j)] = fl[e].v;
             if (keep) P.fval_map[t.far_off + pk * 256 + packet_val_pos<V>(l, j)] = fl[e].src;
             amax_t = std::max(amax_t, std::fabs((double)fl[e].v));
+            nonfinite_t |= !std::isfinite((double)fl[e].v);
             fr[pk * 256 + packet_slot_pos(l, j)] = (uint16_t)fl[e].r;
             fc[pk * 256 + packet_slot_pos(l, j)] = fl[e].c;
           }
         }
-        P.tiles[ti].aexp = (amax_t > 0.0 && std::isfinite(amax_t)) ? std::ilogb(amax_t) + 1 : -1000;
+        // (std::max drops a NaN operand: a NaN value is caught by its own test)
+        P.tiles[ti].aexp = !(nonfinite_t == 0) ? kAexpNonFinite
+                           : (amax_t > 0.0 && std::isfinite(amax_t)) ? std::ilogb(amax_t) + 1 : -1000;
         if (bad) {
 #pragma omp atomic write
           dup_error = true;
@@ -1288,36 +1336,7 @@ template <typename V> struct Builder {
     P.fold_dst.resize(P.fold_row.size());
     for (size_t i = 0; i < P.fold_row.size(); i++) P.fold_dst[i] = orig(P.fold_row[i] + rb) - rb;
     if (perm_in) P.perm = *perm_in;
-    // Which workgroup runs which group.  With two workgroups per CU the dispatcher
-    // places workgroups 0 .. G/2-1 first (one per CU) and G/2 .. G-1 as the second
-    // workgroup of the same CUs: those start 2 us later and -- the older workgroup of a
-    // CU wins its arbitration -- end 5 us later (tools/calib_probe.py).  The expensive
-    // groups of an XCD's run (several tiles, ragged clusters with much halo: the last
-    // clusters of every clustering sweep) therefore go FIRST, and the second workgroup
-    // of a CU is the cheapest partner for its first: longest-processing-time pairing
-    // on the model cost of a group.  Same XCD, same L2 as before.
-    P.launch_order.resize(nc);
-    for (int g = 0; g < nc; g++) P.launch_order[g] = g;
-    if (opt.cost_model && L.full_grid && L.wg_per_cu == 2 && nc % 16 == 0 && env_or("CFS_HIP_LAUNCH_ORDER", 1) != 0) {
-      const ClusterCost cm = L.cluster_cost(opt);
-      std::vector<double> gc(nc, 0.0);
-      for (int g = 0; g < nc; g++) {
-        const int t0 = P.group_ptr[g], t1 = P.group_ptr[g + 1];
-        for (int ti = t0; ti < t1; ti++) gc[g] += (double)(P.tiles[ti].nslots - P.tiles[ti].nown) * cm.per_halo;
-        gc[g] += (double)std::max(0, t1 - t0 - 1) * cm.per_tile;
-        if (t1 > t0) gc[g] += (double)(cost[P.tiles[t1 - 1].row0 + P.tiles[t1 - 1].nown - rb] - cost[P.tiles[t0].row0 - rb]);
-      }
-      const int nper = nc / 8, h = nper / 2;
-      std::vector<int32_t> idx(nper);
-      for (int x = 0; x < 8; x++) {
-        for (int k = 0; k < nper; k++) idx[k] = x * nper + k;
-        std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return gc[a] > gc[b]; });
-        for (int j = 0; j < h; j++) {
-          P.launch_order[x * nper + j] = idx[j];                // first wave: heaviest first
-          P.launch_order[x * nper + h + j] = idx[nper - 1 - j]; // its CU partner: lightest
-        }
-      }
-    }
+    compute_launch_order(L, opt, P.tiles, P.group_ptr, cost, rb, P.launch_order);
   }
 
   // the whole build; cut_only: the caller only wants to compare halo sizes of two row orders
@@ -1616,6 +1635,7 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
 // one's, consecutive in the sweep order).
 template <typename V> struct ScheduleSpace {
   bool valid = false;
+  bool device_only = false; // perm / chunk only: the matrix arrays live on the GPU (cfs_devplan.hpp)
   int rb = 0, re = 0, nchunks = 0;
   std::vector<int32_t> perm, chunk, brp;
   BigVec<int32_t> bci;
@@ -1627,6 +1647,7 @@ template <typename V> struct ScheduleSpace {
   ~ScheduleSpace() { drop(); }
   void drop() {
     valid = false;
+    device_only = false;
     release_async(bci);
     release_async(bva);
     release_async(bsr);
@@ -1677,8 +1698,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
   const bool mirror = opt.mirror_offblock && nranks > 1;
   ScheduleSpace<V> local;
   ScheduleSpace<V> &sp = cache ? *cache : local;
-  if (cache && cache->valid && cache->rb == rb && cache->re == re && cache->nchunks == 2 * nchunks &&
-      opt.group_share.empty()) {
+  if (cache && cache->valid && !cache->device_only && cache->rb == rb && cache->re == re &&
+      cache->nchunks == 2 * nchunks && opt.group_share.empty()) {
     // reuse: same row order, every second cluster boundary; always clustered
     std::vector<int32_t> merged(nchunks + 1);
     for (int g = 0; g <= nchunks; g++) merged[g] = sp.chunk[2 * g];
@@ -1691,6 +1712,7 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
                               nullptr, nullptr, P);
   }
   sp.valid = false;
+  sp.device_only = false;
   std::vector<int32_t> &perm = sp.perm, &chunk = sp.chunk;
   cluster_rows<V>(n, rowptr, colind, rb, re, nchunks, L.shares(opt), perm, chunk, mirror,
                   L.cluster_cost(opt));

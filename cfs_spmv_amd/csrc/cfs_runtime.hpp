@@ -10,6 +10,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -52,7 +53,9 @@ struct Runtime {
   // never called it -- the device that was current in the calling thread at the
   // first use (torch.cuda.set_device(local_rank) of a rank process), never a
   // hard-wired device 0
-  int home = -1;
+  // (atomic: two threads may make the first call of a process at once; the contexts
+  // themselves are created under `mu`, device_ctx)
+  std::atomic<int> home{-1};
 };
 inline Runtime &rt() {
   static Runtime r;
@@ -98,20 +101,24 @@ inline int bind_home(int device) {
   HIPCHK(hipSetDevice(device));
   int rc = device_ctx(device, &c);
   if (rc) return rc;
-  rt().home = device;
+  rt().home.store(device, std::memory_order_release);
   return 0;
 }
 
-// first use without cfs_hip_init(): adopt the caller's current device
+// first use without cfs_hip_init(): adopt the caller's current device (two threads racing
+// here both bind the device that is current in THEIR thread; the later store wins, both
+// contexts exist)
 inline int ensure_home() {
-  if (rt().home >= 0) return 0;
+  if (rt().home.load(std::memory_order_acquire) >= 0) return 0;
   int d = 0;
   HIPCHK(hipGetDevice(&d));
   return bind_home(d);
 }
 inline hipStream_t home_stream() {
-  const int h = rt().home;
-  return h >= 0 ? rt().ctx[h].stream : nullptr;
+  const int h = rt().home.load(std::memory_order_acquire);
+  if (h < 0) return nullptr;
+  std::lock_guard<std::mutex> lk(rt().mu);
+  return rt().ctx[h].stream;
 }
 
 // ---------------------------------------------------------------------------

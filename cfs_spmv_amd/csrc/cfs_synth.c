@@ -56,11 +56,58 @@ typedef struct {
   int knn, bfs;
   long *adj_ptr;
   int *adj;
+  /* tetmesh (kind 2 with var_dof): 1..4 unknowns per node, node_off = first row of a node;
+   * a row couples with ~3/4 of a neighbour node's unknowns, each row its own choice */
+  int var_dof, nnodes;
+  int *node_off;
 } spec_t;
 
 /* strictly-lower column list of row i (ascending, unique).  Returns count. */
 static int lower_cols(const spec_t *sp, int i, int *out, int cap) {
   int cnt = 0;
+  if (sp->kind == 2 && sp->var_dof) {
+    /* tetrahedral-mesh-like, unequal unknowns per node: the rows of one node do NOT repeat
+     * each other's columns (a row keeps an entry of a neighbour node's block with
+     * probability 3/4, decided by the unordered pair of row indices: symmetric) */
+    int lo = 0, hi = sp->nnodes; /* node of row i: last node_off <= i */
+    while (hi - lo > 1) {
+      const int m = (lo + hi) >> 1;
+      if (sp->node_off[m] <= i) lo = m;
+      else hi = m;
+    }
+    const int node = lo;
+    for (long k = sp->adj_ptr[node]; k < sp->adj_ptr[node + 1]; k++) {
+      const int u = sp->adj[k];
+      for (int c = sp->node_off[u]; c < sp->node_off[u + 1]; c++)
+        if (c < i && cnt < cap && (splitmix64(sp->seed ^ 0x7e7a11ULL ^ ((uint64_t)i << 32 | (uint64_t)c)) & 3) != 0)
+          out[cnt++] = c;
+    }
+    for (int c = sp->node_off[node]; c < i; c++)
+      if (cnt < cap) out[cnt++] = c; /* the node's own block is dense */
+    return cnt; /* ascending (neighbours ascend, rows of a node are consecutive) and unique */
+  }
+  if (sp->kind == 3) {
+    /* power-law graph: a heavy-tailed number of lower entries per row (a few rows with
+     * thousands: hubs), half of them inside a window of 2 000 rows (communities), half
+     * preferential -- concentrated on low indices, which become hub COLUMNS (long tails) */
+    const uint64_t h0 = splitmix64(sp->seed ^ ((uint64_t)i * 0x9e3779b97f4a7c15ULL));
+    int k = 8 + (int)(12.0 * (pow(u01(h0), -0.6) - 1.0));
+    if (k > 2000) k = 2000;
+    if (k > i) k = i;
+    for (int q = 0; q < k && cnt < cap; q++) {
+      const uint64_t h = splitmix64(h0 + (uint64_t)(q + 1) * 0xd6e8feb86659fd93ULL);
+      int c;
+      if (q & 1) {
+        const int win = i < 2000 ? i : 2000;
+        c = i - 1 - (int)((h >> 8) % (uint64_t)win);
+      } else {
+        const double v = u01(h);
+        c = (int)((double)i * v * v * v);
+      }
+      if (c >= 0 && c < i) out[cnt++] = c;
+    }
+    goto sort_unique;
+  }
   if (sp->kind == 2) {
     /* unstructured: dof x dof blocks with the lower node neighbours, then the own node */
     const int dof = sp->dof, node = i / dof;
@@ -115,6 +162,7 @@ static int lower_cols(const spec_t *sp, int i, int *out, int cap) {
       }
     }
   }
+sort_unique:
   /* sort + unique */
   for (int a = 1; a < cnt; a++) {
     int v = out[a], b = a - 1;
@@ -180,6 +228,21 @@ static int make_spec(const char *name, double scale, spec_t *sp) {
     sp->knn = 21;
     sp->bfs = !strcmp(name, "unstruct_bfs");
     sp->seed = fnv1a("unstruct"); /* both orders are the SAME graph */
+  } else if (!strcmp(name, "tetmesh")) {
+    /* tetrahedral-mesh-like: the same kind of point-cloud graph (21 nearest neighbours,
+     * breadth-first numbering), but 1..4 unknowns per node (mixed pressure / velocity /
+     * temperature) and rows of a node that are NOT prefixes of one another: the shapes for
+     * which the slot leaders and sibling chains of the tile format pay least */
+    sp->kind = 2;
+    sp->var_dof = 1;
+    sp->dof = 3; /* nominal: nodes = n / 2.8 */
+    sp->n = (int)(1500000 * scale);
+    sp->knn = 21;
+    sp->bfs = 1;
+  } else if (!strcmp(name, "powerlaw")) {
+    /* power-law-degree symmetric graph: hub rows and long tails */
+    sp->kind = 3;
+    sp->n = (int)(1000000 * scale);
   } else {
     return -1;
   }
@@ -199,7 +262,8 @@ static int cmp_u64(const void *a, const void *b) {
   return x < y ? -1 : x > y;
 }
 static int build_cloud(spec_t *sp) {
-  const int N = (sp->n + sp->dof - 1) / sp->dof, K = sp->knn;
+  /* (var_dof: 1..4 unknowns per node, 2.8 on average) */
+  const int N = sp->var_dof ? (int)((double)sp->n / 2.8) + 1 : (sp->n + sp->dof - 1) / sp->dof, K = sp->knn;
   float *px = (float *)malloc(sizeof(float) * 3 * (size_t)N);
   if (!px) return -1;
   for (int v = 0; v < N; v++)
@@ -340,6 +404,17 @@ static int build_cloud(spec_t *sp) {
     sp->adj[k] = (int)(edges[k] & 0xffffffffULL); /* sorted by (higher, lower): in place */
   }
   for (int v = 0; v < N; v++) sp->adj_ptr[v + 1] += sp->adj_ptr[v];
+  if (sp->var_dof) { /* unknowns per node: 20 % 1, 10 % 2, 40 % 3, 30 % 4; n = their sum */
+    sp->nnodes = N;
+    sp->node_off = (int *)malloc(sizeof(int) * ((size_t)N + 1));
+    sp->node_off[0] = 0;
+    for (int v = 0; v < N; v++) {
+      const unsigned r = (unsigned)(splitmix64(sp->seed ^ 0xd0fULL ^ (uint64_t)v) % 10u);
+      const int d = r < 2 ? 1 : (r < 3 ? 2 : (r < 7 ? 3 : 4));
+      sp->node_off[v + 1] = sp->node_off[v] + d;
+    }
+    sp->n = sp->node_off[N];
+  }
   free(edges);
   free(label);
   free(px);
@@ -359,9 +434,9 @@ int cfs_synth_generate(const char *name, double scale, int *n_out,
                        int **colind_out, double **values_out) {
   spec_t sp;
   if (make_spec(name, scale, &sp) != 0) return -1;
-  const int n = sp.n;
   const int CAP = 2048;
   if (sp.kind == 2 && build_cloud(&sp) != 0) return -3;
+  const int n = sp.n; /* (tetmesh: known once the unknowns per node are drawn) */
   /* pass 1: lower counts */
   long *lptr = (long *)calloc((size_t)n + 1, sizeof(long));
 #pragma omp parallel
@@ -437,6 +512,7 @@ int cfs_synth_generate(const char *name, double scale, int *n_out,
   free(upos);
   free(sp.adj_ptr);
   free(sp.adj);
+  free(sp.node_off);
   *n_out = n;
   *nnz_full_out = nnz_full;
   *nnz_low_out = nnz_low;

@@ -53,6 +53,11 @@ def _stream_ptr(stream=None):
 
 FLAG_SHARD_EXCHANGE = 64  # include/cfs_hip.h: CFS_HIP_FLAG_SHARD_EXCHANGE
 FLAG_KEEP_VALUE_MAP = 2048  # CFS_HIP_FLAG_KEEP_VALUE_MAP
+FLAG_HOST_PLAN = 4096  # CFS_HIP_FLAG_HOST_PLAN: build the schedule with the host builder
+DIGEST_WORDS = 20  # CFS_HIP_DIGEST_WORDS
+DIGEST_NAMES = ["tiles", "gfirst", "group_range", "slot_col", "rowinfo", "diag", "slice_meta", "leadlane",
+                "vals", "slots", "cvals", "crows", "ccols", "fold_rec", "fold_idx", "val_map", "cval_map",
+                "diag_map", "window", "device_built"]
 
 
 def make_options(max_slots=0, max_tile_nnz=0, block_threads=0, flags=0):
@@ -169,6 +174,18 @@ class SymMatrix:
 
     def tune(self, kernel=Kernel.SpDMV, tuning=Tuning.Aggressive):
         return True  # the schedule is built at construction
+
+    def digest(self):
+        """developer / test: digests of the schedule's device arrays (cfs_hip_sym_debug_digest)"""
+        w = (C.c_ulonglong * DIGEST_WORDS)()
+        _lib.check(_lib.load().cfs_hip_sym_debug_digest(self._h, w, DIGEST_WORDS))
+        return dict(zip(DIGEST_NAMES, [int(v) for v in w]))
+
+    def plan_note(self):
+        """why the device builder handed the schedule to the host builder ('' = it built it)"""
+        buf = C.create_string_buffer(256)
+        _lib.check(_lib.load().cfs_hip_sym_debug_plan_note(self._h, buf, 256))
+        return buf.value.decode(errors="replace")
 
     def stats(self):
         st = _lib.SymStats()

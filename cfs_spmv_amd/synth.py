@@ -12,6 +12,9 @@ NAMES = ("pdb1HYS", "pwtk", "ldoor", "Flan_1565", "Queen_4147")
 # non-regular stand-ins (SURVEY 7 "structure-faithful synthetic generators"): a random 3-D
 # point cloud, 21 nearest neighbours, 3 dof per node; random / breadth-first numbering
 UNSTRUCTURED = ("unstruct", "unstruct_bfs")
+# tetmesh: the same kind of graph with 1..4 unknowns per node whose rows do not repeat each
+# other's columns; powerlaw: heavy-tailed row lengths, hub columns
+NONREGULAR = ("tetmesh", "powerlaw")
 
 
 def _lib():

@@ -59,6 +59,9 @@ int cfs_hip_device_count(int *count);
  * hard-wired device 0).                                                        */
 int cfs_hip_init(int device);
 int cfs_hip_current_device(int *device); /* the home device */
+/* 1 once a home device is bound; never initialises the runtime itself (the allocator seam asks
+ * before it hands out page-locked host memory: a plain host allocation must not start HIP) */
+int cfs_hip_runtime_bound(void);
 /* stream used internally by the synchronous (host-pointer capable) entry
  * points; created by cfs_hip_init.  The *_async entry points take the caller's
  * hipStream_t verbatim: NULL there means HIP's null stream (which is what
@@ -138,6 +141,13 @@ typedef struct {
  * value array (4 bytes per stored nonzero of device memory): cfs_hip_sym_update_values_*
  * can then refresh the numbers of the matrix without repeating tune()             */
 #define CFS_HIP_FLAG_KEEP_VALUE_MAP 2048
+/* tune() builds the tile schedule ON THE GPU from one upload of the caller's CSR (split,
+ * tile cut, slot tables, virtual rows, leaders, packing: HIP kernels) whenever
+ * the options are covered by the device builder -- everything but HYB far entries, the
+ * deterministic build and the exchange form of a shard.  With this flag the host builder
+ * (cfs_plan.hpp, OpenMP) is used instead; the two produce the same schedule bit for bit
+ * (cfs_hip_sym_debug_digest).                                                          */
+#define CFS_HIP_FLAG_HOST_PLAN 4096
 
 /* ---- tune() for a symmetric matrix
  *      (replaces CSRMatrix::tune -> compress_symmetry ->
@@ -175,7 +185,8 @@ int cfs_hip_sym_create_shard_f32(int n, const int *rowptr, const int *colind,
  * current one; several shards may share a device), each on a stream of its own.
  * The handle behaves like a whole-matrix one: cfs_hip_sym_spmv[_async] take x / y
  * of n entries on the device that was current at create (or host pointers);
- * shards on other devices reach them through peer access.                      */
+ * shards on other devices get a replica of x per SpMV and copy their y block back
+ * (cfs_hip_sym_multi_set_xmode; or reach both through peer access).            */
 int cfs_hip_sym_create_multi_f64(int n, const int *rowptr, const int *colind,
                                  const double *values, int ngpus, const int *devices,
                                  const cfs_hip_options *opt, cfs_hip_sym_t *out);
@@ -183,6 +194,20 @@ int cfs_hip_sym_create_multi_f32(int n, const int *rowptr, const int *colind,
                                  const float *values, int ngpus, const int *devices,
                                  const cfs_hip_options *opt, cfs_hip_sym_t *out);
 int cfs_hip_sym_num_gpus(cfs_hip_sym_t h, int *ngpus); /* shards of the handle (1: plain) */
+/* How the shards of a multi-device handle that live on ANOTHER device than its home reach x / y.
+ * REPLICATE (default; env CFS_MULTI_X=replicate): x is replicated -- one peer copy home ->
+ * device per shard and SpMV, kernels gather x and write their y block in local HBM, one peer
+ * copy brings the block home (north_star: "x replicated").  PEER (CFS_MULTI_X=peer): kernels
+ * read x / write y in the home device's memory through peer access over xGMI, no copies.
+ * REPLICATE_ALL copies for shards on the home device too (tests on a one-GPU box).
+ * NOTE: with more than one physical device neither form has run on hardware yet (the build
+ * and test boxes have one GPU); treat cross-device operation as unverified.           */
+#define CFS_HIP_XMODE_PEER 0
+#define CFS_HIP_XMODE_REPLICATE 1
+#define CFS_HIP_XMODE_REPLICATE_ALL 2
+int cfs_hip_sym_multi_set_xmode(cfs_hip_sym_t h, int xmode);
+/* devices[g] = device of shard g (may be NULL); *distinct = number of distinct devices */
+int cfs_hip_sym_multi_devices(cfs_hip_sym_t h, int *devices, int capacity, int *distinct);
 /* nnz_low-balanced row boundaries (multiples of 16, csr_matrix.tpp:418) for
  * sharding; row_splits has nranks+1 entries.                                 */
 int cfs_hip_sym_balanced_splits(int n, const int *rowptr, const int *colind,
@@ -248,6 +273,35 @@ int cfs_hip_sym_spmv_phases_async(cfs_hip_sym_t h, void *y_block_dev,
                                   const void *x_dev, void *send_buf_dev,
                                   int phases, void *stream);
 
+/* ---- native exchange between the row blocks of one process's devices: the north-star's
+ *      reduce-scatter over xGMI, and the y -> x all-gather of a solver loop, without Python.
+ *      (The reference has no exchange beyond its barrier between colours,
+ *      csr_matrix.tpp:3018; what crosses a block boundary here are its direct conflicts,
+ *      :1443-1451.)  Transports: RCCL (one communicator per device, ncclCommInitAll;
+ *      librccl.so is loaded at the first use, the library does not link against it) and PEER
+ *      (plain kernels / copies over peer access: what several ranks on ONE device -- the
+ *      test boxes -- use, RCCL refusing two ranks per device; also the fall-back when RCCL
+ *      cannot be loaded).  AUTO = RCCL when the devices are distinct and it loads.
+ *      NOTE: with more than one rank the RCCL transport has not run on hardware yet.      */
+typedef struct cfs_hip_comm_s *cfs_hip_comm_t;
+#define CFS_HIP_TRANSPORT_AUTO 0
+#define CFS_HIP_TRANSPORT_RCCL 1
+#define CFS_HIP_TRANSPORT_PEER 2
+/* ranks 0..ndev-1 on devices[] (NULL: the visible devices round-robin from the current one) */
+int cfs_hip_comm_create(int ndev, const int *devices, int transport, cfs_hip_comm_t *out);
+int cfs_hip_comm_info(cfs_hip_comm_t c, int *ndev, int *transport);
+int cfs_hip_comm_destroy(cfs_hip_comm_t c);
+/* sum-reduce-scatter: rank g contributes send[g] (ndev * count values, on its device) and
+ * receives the g-th block of the sum in recv[g] (count values); enqueued on streams[g]     */
+int cfs_hip_comm_reduce_scatter(cfs_hip_comm_t c, void *const *send, void *const *recv, size_t count,
+                                int value_bytes, void *const *streams);
+/* all-gather: recv[g] (ndev * count values) = the blocks send[0..ndev-1] (count values each) */
+int cfs_hip_comm_allgather(cfs_hip_comm_t c, void *const *send, void *const *recv, size_t count,
+                           int value_bytes, void *const *streams);
+/* before rank `rank` overwrites its send buffer on `stream`: wait until the previous
+ * collective has consumed it (PEER transport: other ranks' kernels read it)                */
+int cfs_hip_comm_wait_consumed(cfs_hip_comm_t c, int rank, void *stream);
+
 /* ---- introspection (A->nnz(), A->size(), and what bench.py needs) --------- */
 typedef struct {
   int n;               /* matrix order                                    */
@@ -296,6 +350,18 @@ int cfs_hip_sym_debug_timeline(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
 int cfs_hip_sym_debug_group_features(cfs_hip_sym_t h, long long *out, int capacity_words,
                                      int *ngroups);
 
+/* developer / test: 64-bit FNV-1a digests of the device arrays of a handle's schedule, over
+ * their logical lengths, in this order: tiles (aexp masked), launch-slot first tiles, launch-
+ * slot tile ranges, slot_col, rowinfo, diag, slice_meta, leadlane, vals, slots, cvals, crows,
+ * ccols, fold records, fold remainder lists, val_map, cval_map, diag_map (0 when absent).  A
+ * schedule built on the GPU and one built by the host builder for the same matrix and options
+ * have equal digests.  words[CFS_HIP_DIGEST_WORDS - 1] = 1 if the handle's schedule was built
+ * on the GPU.                                                                           */
+#define CFS_HIP_DIGEST_WORDS 20
+int cfs_hip_sym_debug_digest(cfs_hip_sym_t h, unsigned long long *words, int capacity_words);
+/* why the device builder handed this handle's schedule to the host builder ("" = it built it) */
+int cfs_hip_sym_debug_plan_note(cfs_hip_sym_t h, char *buf, int capacity);
+
 /* ---- host-only self-check of the tile schedule (needs no GPU): builds the
  *      schedule tune() would upload, decodes it back to (row, col, value)
  *      triples and compares them with the strict lower triangle of the input;
@@ -340,6 +406,15 @@ int cfs_hip_csr_spmv(cfs_hip_csr_t h, void *y, const void *x);
 int cfs_hip_csr_spmv_async(cfs_hip_csr_t h, void *y_dev, const void *x_dev,
                            void *stream);
 int cfs_hip_csr_destroy(cfs_hip_csr_t h);
+/* The general CSR kernel exists in two forms -- a workgroup per block of rows (products staged
+ * in LDS between two barriers) and a wave per chunk of rows (no workgroup barrier, the next
+ * chunk's loads in flight) -- within a few per cent of each other, the order depending on the
+ * matrix and the box: the FIRST SpMV of a handle with >= 1M nonzeros times five SpMVs of each
+ * (y is fully overwritten by either) and keeps the faster.  CFS_HIP_CSR_KERNEL=block|wave
+ * pins the form.                                                                        */
+#define CFS_HIP_CSR_FORM_BLOCK 0
+#define CFS_HIP_CSR_FORM_WAVE 1
+int cfs_hip_csr_kernel_form(cfs_hip_csr_t h, int *form, int *measured);
 
 /* ---- HIP-event timing on the stream the kernels run on (bench.py) --------- */
 int cfs_hip_event_create(void **ev);

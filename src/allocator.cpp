@@ -2,7 +2,8 @@
 // (reference seam: src/allocator.cpp:8-43).  gpu = HBM through the C ABI.  cpu =
 // 64-byte aligned host memory as in the reference; vectors of 64 KiB .. 256 MiB
 // come from the page-locked pool of the runtime (CFS_HIP_MEM_PINNED) once a
-// device is bound, so that an unmodified caller that hands its host x / y to
+// device is bound (cfs_hip_runtime_bound: creating a matrix binds it; an allocation
+// alone never starts HIP), so that an unmodified caller that hands its host x / y to
 // SpDMV (test/test_spmv_mmf.cpp:82-83) is DMA-ed in place instead of being
 // copied through a staging block.  Failures print and exit(1), like the
 // reference does.
@@ -31,10 +32,8 @@ void *internal_alloc(size_t bytes, Platform platform) {
     if (cfs_hip_alloc(bytes, CFS_HIP_MEM_DEVICE, &pointer) != 0) die("cfs_hip_alloc() failed");
     return pointer;
   }
-  int dev = -1;
   if (bytes >= kPinnedMin && bytes <= kPinnedMax && getenv("CFS_NO_PINNED") == nullptr &&
-      cfs_hip_device_count(&dev) == 0 && dev > 0 &&
-      cfs_hip_alloc(bytes, CFS_HIP_MEM_PINNED, &pointer) == 0)
+      cfs_hip_runtime_bound() && cfs_hip_alloc(bytes, CFS_HIP_MEM_PINNED, &pointer) == 0)
     return pointer;
   pointer = nullptr;
   if (posix_memalign(&pointer, 64, bytes ? bytes : 64) != 0) {

@@ -1,0 +1,142 @@
+"""tune() on the GPU (cfs_devplan.hpp): the schedule the HIP kernels build from
+one upload of the caller's CSR is BIT-IDENTICAL to the one the host builder (cfs_plan.hpp)
+uploads -- tiles, slot tables, virtual rows, slice metadata, leader lanes, packet streams, COO
+leftovers, fold records -- on the stand-ins, on randomised matrices of many shapes and option
+sets (the cases of test_plan_random.py) and on mirrored shards; and its SpMV agrees with the
+oracle.  The reference's counterpart of this work is the host-side preprocessing of
+conflict_free_aposteriori, include/matrix/csr_matrix.tpp:1204-1639."""
+import numpy as np
+import pytest
+
+import cfs_spmv_amd as cfs
+from cfs_spmv_amd import _lib, synth
+from rand_matrices import random_matrix
+
+pytestmark = pytest.mark.gpu
+
+NO_CALIBRATE = 32
+
+
+@pytest.fixture(autouse=True)
+def _torch_first():
+    """torch brings a HIP runtime of its own: it has to initialise before libcfs_hip.so's"""
+    import torch
+    torch.cuda.init()
+    torch.cuda.set_device(0)
+    yield
+
+
+def _both(n, rp, ci, va, flags=0, slots=0, block=0, row_splits=None, rank=0):
+    """(device-built handle, host-built handle) for the same matrix and options"""
+    kw = dict(row_splits=row_splits, rank=rank)
+    D = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(slots, 0, block, flags | NO_CALIBRATE), **kw)
+    H = cfs.SymMatrix(n, rp, ci, va,
+                      options=cfs.make_options(slots, 0, block, flags | NO_CALIBRATE | cfs.FLAG_HOST_PLAN), **kw)
+    return D, H
+
+
+def _assert_same(D, H, what):
+    d, h = D.digest(), H.digest()
+    assert h["device_built"] == 0
+    assert d["device_built"] == 1, f"{what}: the device builder handed over to the host builder: {D.plan_note()}"
+    diff = [k for k in d if k != "device_built" and d[k] != h[k]]
+    sd, sh = D.stats(), H.stats()
+    assert not diff, (what, diff, {k: (sd[k], sh[k]) for k in sd if sd[k] != sh[k]})
+    for k in ("ntiles", "nslices", "halo_slots", "fold_rows", "bytes_streamed", "lds_bytes", "ngroups",
+              "mirror_entries", "nnz_low", "nnz_full"):
+        assert sd[k] == sh[k], (what, k, sd[k], sh[k])
+
+
+@pytest.mark.parametrize("name,scale", [("pwtk", 0.05), ("pwtk", 1.0), ("ldoor", 0.05), ("Flan_1565", 0.03),
+                                        ("Flan_1565", 0.3), ("pdb1HYS", 0.3), ("unstruct", 0.05)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_device_schedule_equals_host_schedule_on_stand_ins(name, scale, dtype):
+    n, rp, ci, va, _ = synth.generate(name, scale)
+    va = va.astype(dtype)
+    D, H = _both(n, rp, ci, va)
+    _assert_same(D, H, (name, scale, dtype.__name__))
+    # ... and it computes the same y (same arrays, same kernel: bit for bit in one launch order)
+    import torch
+    x = torch.from_numpy(synth.make_x(n, 42, dtype)).cuda()
+    yd = torch.empty(n, dtype=x.dtype, device="cuda")
+    yh = torch.empty_like(yd)
+    D.dense_vector_multiply(yd, x)
+    H.dense_vector_multiply(yh, x)
+    torch.cuda.synchronize()
+    tol = 1e-12 if dtype == np.float64 else 1e-5
+    scale_ = torch.maximum(yh.abs(), torch.tensor(1.0, dtype=x.dtype, device="cuda"))
+    assert float(((yd - yh).abs() / scale_).max()) <= 10 * tol
+    D.close()
+    H.close()
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_device_schedule_equals_host_schedule_on_random_matrices(seed):
+    rng = np.random.default_rng(5000 + seed)
+    kind = ["band", "random", "nodes", "hub"][seed % 4]
+    n = int(rng.integers(300, 6000))
+    n, A = random_matrix(rng, n, kind)
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    va = A.data.astype(np.float64 if seed % 3 else np.float32)
+    block = int(rng.choice([0, 256, 512, 1024]))
+    slots = int(rng.choice([0, 256, 1024, 2560]))
+    flags = int(rng.choice([0, 0, 8, 16]))  # default order choice / natural / clustered
+    if seed % 5 == 0:
+        flags |= cfs.FLAG_KEEP_VALUE_MAP
+    try:
+        D, H = _both(n, rp, ci, va, flags, slots, block)
+    except _lib.CfsHipError as e:
+        assert "dense row" in str(e), str(e)
+        return
+    if D.digest()["device_built"] == 0:  # long / dense rows: the host builder took it
+        assert kind == "hub", (kind, n, block, slots, flags, D.plan_note())
+        return
+    _assert_same(D, H, (kind, n, block, slots, flags))
+    D.close()
+    H.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3, 8])
+def test_device_schedule_of_mirrored_shards(nranks):
+    import torch
+    from oracle import oracle
+    n, rp, ci, va, _ = synth.generate("Flan_1565", 0.05)
+    rs = cfs.balanced_splits(n, rp, ci, nranks)
+    x_host = synth.make_x(n)
+    x = torch.from_numpy(x_host).cuda()
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x_host)
+    for rank in range(nranks):
+        D, H = _both(n, rp, ci, va, row_splits=rs, rank=rank)
+        _assert_same(D, H, ("shard", nranks, rank))
+        rows = int(rs[rank + 1] - rs[rank])
+        y = torch.full((rows,), float("nan"), dtype=torch.float64, device="cuda")
+        D.spmv_phases(y, x, None, 3)
+        torch.cuda.synchronize()
+        ref = y_ld[rs[rank]:rs[rank + 1]]
+        den = np.maximum(np.abs(ref), absrow[rs[rank]:rs[rank + 1]])
+        assert float(np.max(np.abs(y.cpu().numpy() - ref) / den)) <= 1e-12
+        D.close()
+        H.close()
+
+
+def test_device_builder_hands_unsorted_rows_to_the_host_builder():
+    """rows whose columns do not ascend are outside the device builder's contract: it must
+    notice (on the GPU) and hand over, never build a wrong schedule"""
+    import torch
+    from oracle import oracle
+    n, rp, ci, va, _ = synth.generate("pwtk", 0.02)
+    ci, va = ci.copy(), va.copy()
+    for i in range(0, n, 7):  # reverse every 7th row
+        b, e = rp[i], rp[i + 1]
+        ci[b:e] = ci[b:e][::-1]
+        va[b:e] = va[b:e][::-1]
+    A = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=NO_CALIBRATE))
+    assert A.digest()["device_built"] == 0
+    x_host = synth.make_x(n)
+    x = torch.from_numpy(x_host).cuda()
+    y = torch.empty(n, dtype=torch.float64, device="cuda")
+    A.dense_vector_multiply(y, x)
+    torch.cuda.synchronize()
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x_host)
+    assert float(np.max(np.abs(y.cpu().numpy() - y_ld) / np.maximum(np.abs(y_ld), absrow))) <= 1e-12
+    A.close()

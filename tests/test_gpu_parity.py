@@ -28,7 +28,7 @@ def _gpu_spmv(A, x, torch, garbage=777.0):
     return yd.cpu().numpy()
 
 
-def _check(n, rp, ci, va, x, dtype, options=None, threads=(1, 4)):
+def _check(n, rp, ci, va, x, dtype, options=None, threads=(1, 4), ref_criterion=True):
     import cfs_spmv_amd as cfs
     from oracle import oracle
     torch = _torch()
@@ -47,21 +47,30 @@ def _check(n, rp, ci, va, x, dtype, options=None, threads=(1, 4)):
         assert scaled_err(y, y_ref.astype(np.float64), absrow) <= tol, f"T={T}"
         o.close()
     # the reference's own test: SSS result vs plain CSR result, element-wise
-    y_csr = oracle.csr_spmv(n, rp, ci, va, x)
-    well = absrow <= 1e3 * np.abs(y_csr)  # rows that do not cancel
-    assert np.all(np.abs(y[well] - y_csr[well]) <= REF_EPS[dtype] * np.abs(y[well]))
+    if ref_criterion:
+        y_csr = oracle.csr_spmv(n, rp, ci, va, x)
+        well = absrow <= 1e3 * np.abs(y_csr)  # rows that do not cancel
+        assert np.all(np.abs(y[well] - y_csr[well]) <= REF_EPS[dtype] * np.abs(y[well]))
     A.close()
     return y
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("name,scale", [("pdb1HYS", 0.25), ("pwtk", 0.05), ("ldoor", 0.02),
-                                        ("Flan_1565", 0.01)])
+                                        ("Flan_1565", 0.01),
+                                        # non-regular shapes: unequal unknowns
+                                        # per node, rows that are not prefixes of each other; a
+                                        # power-law graph with hub rows and long tails
+                                        ("tetmesh", 0.03), ("powerlaw", 0.05)])
 def test_synth_parity(name, scale, dtype):
     from cfs_spmv_amd import synth
     n, rp, ci, va, _ = synth.generate(name, scale)
     x = synth.make_x(n)
-    _check(n, rp, ci, va, x, dtype)
+    # (the reference's element-wise isEqual compares against cpu_mv, which adds a row in the
+    # working precision in stored order: on the hub rows of the power-law graph -- 16 000
+    # entries -- that sum itself is only good to ~1e-3 in single precision, while the 1e-5 bound
+    # against the long-double row sums above holds)
+    _check(n, rp, ci, va, x, dtype, ref_criterion=not (name == "powerlaw" and dtype == np.float32))
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
@@ -146,6 +155,33 @@ def test_csr_general_parity():
             y_ld, absrow = oracle.csr_spmv_ld(m, rp, ci, va, np.resize(x, k))
             assert scaled_err(y, y_ld, absrow) <= TOL[dtype]
             G.close()
+
+
+@pytest.mark.parametrize("form", ["wave", "block"])
+@pytest.mark.parametrize("name,scale", [("pdb1HYS", 0.25), ("pwtk", 0.05), ("ldoor", 0.02), ("Flan_1565", 0.01),
+                                        ("Queen_4147", 0.005), ("tetmesh", 0.03), ("powerlaw", 0.05)])
+def test_csr_general_parity_on_stand_ins(name, scale, form, monkeypatch):
+    """both forms of the general CSR kernel (wave-stream: the default; workgroup-per-block) on
+    the full CSR of the stand-ins -- short rows, 7-dof blocks, hub rows of > 10 000 entries
+    (cfs_csr_longrow_kernel), empty tails -- against the long-double row sums"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from oracle import oracle
+    torch = _torch()
+    monkeypatch.setenv("CFS_HIP_CSR_KERNEL", form)
+    n, rp, ci, va, _ = synth.generate(name, scale)
+    for dtype in (np.float64, np.float32):
+        v = va.astype(dtype)
+        x = synth.make_x(n, 42, dtype)
+        G = cfs.CsrMatrix(n, n, rp, ci, v)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.full((n,), float("nan"), dtype=xd.dtype, device="cuda")
+        G.dense_vector_multiply(yd, xd)
+        G.dense_vector_multiply(yd, xd)
+        torch.cuda.synchronize()
+        y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, v, x)
+        assert scaled_err(yd.cpu().numpy(), y_ld, absrow) <= TOL[dtype], (name, form, dtype.__name__)
+        G.close()
 
 
 @pytest.mark.parametrize("nranks", [2, 4])

@@ -179,6 +179,38 @@ def test_deterministic_mode_with_wide_value_range():
     M.close()
 
 
+@pytest.mark.parametrize("where", ["x", "a"])
+@pytest.mark.parametrize("bad", [float("nan"), float("inf")])
+def test_deterministic_mode_propagates_nan_and_inf(where, bad):
+    """a NaN / Inf in x or among the values has no fixed-point image: the rows it reaches must
+    read NaN / Inf (as the floating-point path gives), never plausible finite numbers -- a
+    diverging solver on a deterministic handle has to see that it diverged"""
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    torch = _torch()
+    n, rp, ci, va, _ = synth.generate("pwtk", 0.02)
+    va = va.copy()
+    x = synth.make_x(n)
+    i = n // 2
+    if where == "x":
+        x[i] = bad
+    else:
+        lo = [j for j in range(rp[i], rp[i + 1]) if ci[j] < i]
+        j = lo[len(lo) // 2]
+        c = ci[j]
+        va[j] = bad  # the stored lower entry (i, c) ...
+        for q in range(rp[c], rp[c + 1]):  # ... and its image, so that the matrix stays symmetric
+            if ci[q] == i:
+                va[q] = bad
+    y_plain = _spmv(cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=FLAG_NO_CAL)), x, torch)
+    y_det = _spmv(cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=FLAG_DET | FLAG_NO_CAL)), x, torch)
+    reached = ~np.isfinite(y_plain)  # the rows the bad number reaches in the default mode
+    assert reached.any()
+    assert not np.isfinite(y_det[reached]).any(), "finite garbage where the default mode has NaN / Inf"
+    # ... and rows of tiles it does not reach are still numbers
+    assert np.isfinite(y_det).sum() > 0.5 * n
+
+
 @pytest.mark.parametrize("ngpus", [2, 3])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_multi_device_handle_on_one_device(ngpus, dtype):
@@ -204,6 +236,19 @@ def test_multi_device_handle_on_one_device(ngpus, dtype):
     yh = np.full(n, 3.0, dtype=dtype)
     A.dense_vector_multiply_host(yh, x)
     assert scaled_err(yh, y_ld, absrow) <= TOL[dtype]
+    # how shards reach x / y (cfs_hip_sym_multi_set_xmode): replicated x + local y block copied
+    # home (REPLICATE_ALL = 2 forces the copies for shards on the home device too: the copy
+    # path of a multi-GPU node, exercised on this one device), and peer access (0); all three
+    # compute the same product
+    lib = _lib.load()
+    nd = C.c_int()
+    devs = (C.c_int * ngpus)()
+    _lib.check(lib.cfs_hip_sym_multi_devices(A._h, devs, ngpus, C.byref(nd)))
+    assert nd.value == 1 and list(devs) == [0] * ngpus
+    for mode in (2, 0, 1):
+        _lib.check(lib.cfs_hip_sym_multi_set_xmode(A._h, mode))
+        for garbage in (1.0, -2.0):
+            assert scaled_err(_spmv(A, x, torch, garbage=garbage), y_ld, absrow) <= TOL[dtype], mode
     A.close()
 
 
@@ -222,6 +267,12 @@ def test_cxx_driver_with_cfs_num_gpus(tmp_path):
     r = subprocess.run([os.path.join(ROOT, "build", "bench_spmv_mmf"), p, "2", "32"],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0 and "format: HYB" in r.stdout and "gpus: 2" in r.stdout, r.stdout + r.stderr
+    assert "devices: 1" in r.stdout  # hbm_pct is taken against the DISTINCT devices (one here)
+    # the copy path of a multi-GPU node (replicated x, y blocks copied home) behind the drivers
+    env["CFS_MULTI_X"] = "replicate_all"
+    r = subprocess.run([os.path.join(ROOT, "build", "test_spmv_mmf"), p, "1"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout + r.stderr
 
 
 def test_host_pointer_path_uses_the_pinned_pool():
