@@ -882,6 +882,7 @@ int place(const Input<V> &in, int rb, int re, bool mirror, const std::vector<int
   S.nl = in.nl;
   const int rows = S.rows;
   int rc;
+  cfs_plan::PhaseTimer pt;
   if (perm_h) {
     std::vector<int32_t> inv((size_t)rows);
 #pragma omp parallel for schedule(static) num_threads(cfs_plan::host_threads())
@@ -895,6 +896,7 @@ int place(const Input<V> &in, int rb, int re, bool mirror, const std::vector<int
       (rc = S.brp.alloc(((size_t)rows + 2) * 4)) || (rc = S.bci.alloc((nl + 1) * 4)) ||
       (rc = S.lcnt.alloc((size_t)rows * 4 + 4)) || (rc = S.firstcol.alloc((size_t)rows * 4 + 4)))
     return rc;
+  pt.lap("  place: inverse order, buffers");
   HIPCHK(hipMemsetAsync(S.dsrc.p, 0xff, (size_t)rows * 4 + 4, 0));
   HIPCHK(hipMemsetAsync(ctr.p, 0, C_COUNT * 8, 0));
   const int nr = in.row_hi - in.row_lo;
@@ -926,11 +928,12 @@ int place(const Input<V> &in, int rb, int re, bool mirror, const std::vector<int
                        (const int32_t *)S.brp.p, (const int32_t *)S.bci.p, (int32_t *)S.lcnt.p,
                        (int32_t *)S.firstcol.p, (int *)flags.p);
   HIPCHK(hipGetLastError());
+  S.h_lcnt.assign((size_t)rows + 1, 0);
+  HIPCHK(hipMemcpy(S.h_lcnt.data(), S.lcnt.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
+  pt.lap("  place: keys, sort, rows (device)");
   // the sort's inputs are not needed any more
   S.keys = DevBuf();
   S.kv = DevBuf();
-  S.h_lcnt.assign((size_t)rows + 1, 0);
-  HIPCHK(hipMemcpy(S.h_lcnt.data(), S.lcnt.p, (size_t)rows * 4, hipMemcpyDeviceToHost));
   int f[F_COUNT];
   if ((rc = read_flags(flags, f))) return rc;
   if (any_flag(f, why)) return kUseHost;
@@ -945,6 +948,7 @@ int place(const Input<V> &in, int rb, int re, bool mirror, const std::vector<int
   for (int r = 0; r < rows; r++)
     S.cost[r + 1] = S.cost[r] + (int64_t)S.h_lcnt[r] * (int64_t)(sizeof(V) + 2) + (int64_t)(4 + 3 * sizeof(V)) +
                     2 * (int64_t)sizeof(V);
+  pt.lap("  place: frees, cost prefix");
   return 0;
 }
 

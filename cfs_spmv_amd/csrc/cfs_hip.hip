@@ -155,22 +155,24 @@ __device__ __forceinline__ uint32_t slot_block(unsigned long long leaders, int c
 // The y window of a tile.  Default: one fp64 word per slot, ds_add_f64 -- the order in
 // which the waves' updates of a slot arrive varies from run to run, and so do the last
 // bits of y.  DETERMINISTIC (CFS_HIP_FLAG_DETERMINISTIC): every contribution p is
-// turned into a fixed-point number of 2 x 40 bits below a per-tile scale 2^e and added
+// turned into a fixed-point number of 2 x 40 bits below a PER-SLOT scale 2^e and added
 // with INTEGER atomics (hi and lo word of the slot): integer addition is associative,
-// so the sums -- and y -- are bit-identical whatever the order.  The scale covers the
-// largest possible row sum of the tile (e = exponent of max|a| + exponent of max|x| in
-// the window + 12 + 16 bits of head-room in the words themselves); a contribution
-// keeps 2^-68 of the largest product of its tile, i.e. full fp64 precision for rows
-// down to 2^-15 of it.
+// so the sums -- and y -- are bit-identical whatever the order.  e = (exponent bound of
+// the 1-norm of the slot's matrix row, cfs_plan: 2^ex > sum_j |a_ij|) + (exponent of
+// the largest |x| in the tile's window): a bound of EVERY partial sum of the slot, so
+// the hi word never needs more than 40 bits, and a contribution keeps 2^-80 of its
+// own row's scale -- the precision does not depend on how the matrix is scaled
+// (round 2 used one scale per tile: rows 2^-15 below the tile's largest lost bits).
 template <bool DET> struct YWin {
   double *y;         // !DET: fp64 sums.  DET: the hi words (as long long)
   long long *lo;     // DET: the lo words
-  double inv;        // DET: 2^(40 - e)
+  const short *ex;   // DET: per slot, exponent bound of the row's 1-norm (LDS)
+  int xe;            // DET: exponent of the window's largest |x| (|x| < 2^xe), wave-uniform
   __device__ __forceinline__ void add(unsigned slot, double p) const {
     if (!DET) {
       atomicAdd(&y[slot], p);
     } else {
-      const double q = p * inv; // exact: inv is a power of two
+      const double q = ldexp(p, 40 - ((int)ex[slot] + xe)); // exact: a power of two
       const double h = trunc(q);
       const long long hi = (long long)h;
       const long long l2 = (long long)rint((q - h) * 0x1p40); // q - h is exact
@@ -186,11 +188,14 @@ template <bool DET> struct YWin {
       lo[slot] = 0;
     }
   }
-  // value of a slot; unscale = 2^(e - 40)
-  __device__ __forceinline__ double get(unsigned slot, double unscale) const {
+  // value of a slot; mul = 1, or NaN when the window of x held a NaN / Inf
+  __device__ __forceinline__ double get(unsigned slot, double mul) const {
     if (!DET) return y[slot];
     const long long hi = reinterpret_cast<const long long *>(y)[slot];
-    return ((double)hi + (double)lo[slot] * 0x1p-40) * unscale;
+    const int e = (int)ex[slot];
+    // (a row that holds a NaN / Inf has no fixed-point image either: it reads NaN)
+    if (e >= cfs_plan::kExpNonFinite) return __longlong_as_double(0x7ff8000000000000ll);
+    return ldexp((double)hi + (double)lo[slot] * 0x1p-40, e + xe - 40) * mul;
   }
 };
 // 2^k as a double, k clamped to the normal range
@@ -298,7 +303,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
                         const uint16_t *__restrict__ a_frows, const int32_t *__restrict__ a_fcols,
                         V *__restrict__ a_strip, const int a_row_begin, const int a_lds_slots,
                         const V *__restrict__ x, V *__restrict__ y,
-                        unsigned long long *__restrict__ dbg) {
+                        unsigned long long *__restrict__ dbg, const short *__restrict__ a_slot_exp) {
   // every array is a separate __restrict__ argument: read-only metadata at
   // wave-uniform addresses then becomes scalar loads (s_load), off the vector
   // memory counter the matrix stream is pipelined on
@@ -331,8 +336,10 @@ __global__ void __launch_bounds__(BLOCK, 4)
   YWin<DET> yl;
   yl.y = reinterpret_cast<double *>(cfs_smem);
   yl.lo = reinterpret_cast<long long *>(cfs_smem) + (DET ? d.lds_slots : 0);
-  yl.inv = 1.0;
   V *xl = reinterpret_cast<V *>(yl.y + (DET ? 2 : 1) * d.lds_slots);
+  short *exl = reinterpret_cast<short *>(xl + d.lds_slots); // DET: per-slot scale exponents
+  yl.ex = exl;
+  yl.xe = 0;
   if (DET) { // exponent of max |x| in the window: two words, tiles alternate
     if (threadIdx.x == 0) cfs_ticket[2] = cfs_ticket[3] = 0;
     __syncthreads();
@@ -367,6 +374,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
   // would otherwise issue 78 % of its start-up loads for nothing.
   static_assert(U <= cfs_plan::kSlotsPerThread, "U");
   V xr[U];
+  short er[DET ? U : 1]; // DET: the slots' scale exponents, fetched with the slot table
   bool first_gather = true;
   auto gather_x = [&](const Tile &tn) {
     // every load is unconditional (clamped index): a load under a divergent
@@ -378,6 +386,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
     for (int k = 0; k < U; ++k) {
       const int i = min(tid + k * BLOCK, tn.nslots - 1);
       idx[k] = d.slot_col[tn.slot_off + i]; // slot_col is padded by one entry
+      if (DET) er[k] = a_slot_exp[tn.slot_off + i];
     }
     if (dbg && tid == 0 && first_gather) { // diagnostic: when did the slot table arrive?
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -426,6 +435,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
       if (i < nslots) {
         xl[i] = xr[k];
         yl.zero(i);
+        if (DET) exl[i] = er[k];
       }
     }
     if (DET) { // biased exponent field of the largest |x| this thread brought in
@@ -485,18 +495,13 @@ __global__ void __launch_bounds__(BLOCK, 4)
     __syncthreads();
     double det_unscale = 1.0;
     if (DET) {
-      // |a| < 2^aexp (plan), |x| < 2^(E - 1022) (window), 12 bits for the longest row sum
+      // |x| < 2^(E - 1022) in this window; the slots bring their own row bound (YWin)
       const int xe = __builtin_amdgcn_readfirstlane(cfs_ticket[2 + det_parity]);
-      const int e = t.aexp + (xe - 1022) + 12;
-      yl.inv = pow2_double(40 - e);
-      det_unscale = pow2_double(e - 40);
-      // a NaN / Inf in the window of x (exponent field 2047) or among the tile's values (plan:
-      // aexp = kAexpNonFinite) has no fixed-point image: every row of the tile reads NaN,
-      // as the floating-point path would propagate it -- never plausible finite garbage
-      if (xe >= 2047 || t.aexp >= cfs_plan::kAexpNonFinite) {
-        yl.inv = 0.0;
-        det_unscale = __longlong_as_double(0x7ff8000000000000ll);
-      }
+      yl.xe = xe - 1022;
+      // a NaN / Inf in the window of x (exponent field 2047) has no fixed-point image: every
+      // row of the tile reads NaN, as the floating-point path would propagate it -- never
+      // plausible finite garbage
+      if (xe >= 2047) det_unscale = __longlong_as_double(0x7ff8000000000000ll);
       det_parity ^= 1;
       if (tid == 0) cfs_ticket[2 + det_parity] = 0; // the next tile's word (see the header comment)
     }
@@ -738,7 +743,10 @@ __global__ void __launch_bounds__(256)
 // a whole-workgroup strided sum.
 constexpr int kCsrNnz = 4096;  // products per workgroup (32 KiB fp64)
 constexpr int kCsrRows = 1024; // rows per block (row pointers in LDS)
-template <typename V>
+// WIDE: a lane loads PAIRS of consecutive entries (16-byte value loads, 8-byte column loads:
+// half as many load instructions for the same bytes; the gathers of a wave still walk
+// consecutive entries)
+template <typename V, bool WIDE = false>
 __global__ void __launch_bounds__(256)
     cfs_csr_stream_kernel(const int32_t *__restrict__ blk_row, int nblocks,
                           const int32_t *__restrict__ rowptr,
@@ -749,32 +757,63 @@ __global__ void __launch_bounds__(256)
   __shared__ int32_t rps[kCsrRows + 1];
   const int tid = threadIdx.x;
   constexpr int PER = kCsrNnz / 256;
+  typedef V V2 __attribute__((ext_vector_type(2)));
+  typedef int I2 __attribute__((ext_vector_type(2)));
   for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
     const int r0 = blk_row[b], r1 = blk_row[b + 1];
     const int p0 = rowptr[r0], p1 = rowptr[r1];
     const int n = p1 - p0;
     if (n <= kCsrNnz) {
-      V v[PER];
-      int c[PER];
       const int nr = r1 - r0;
       int rpv[kCsrRows / 256 + 1];
 #pragma unroll
       for (int u = 0; u <= kCsrRows / 256; ++u) rpv[u] = rowptr[r0 + min(tid + u * 256, nr)];
+      if (WIDE) {
+        constexpr int PW = PER / 2;
+        V2 v2[PW];
+        I2 c2[PW];
+        const int qmax = max(n - 1, 0) & ~1; // last even entry index (the arrays are padded)
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int q = min(tid + u * 256, max(n, 1) - 1);
-        v[u] = __builtin_nontemporal_load(values + p0 + q);
-        c[u] = __builtin_nontemporal_load(colind + p0 + q);
+        for (int u = 0; u < PW; ++u) {
+          const int q = min(2 * (tid + u * 256), qmax);
+          v2[u] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(values + p0 + q));
+          c2[u] = __builtin_nontemporal_load(reinterpret_cast<const I2 *>(colind + p0 + q));
+        }
+#pragma unroll
+        for (int u = 0; u <= kCsrRows / 256; ++u)
+          if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
+        V xa[PW], xb[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+          const int q = min(2 * (tid + u * 256), qmax);
+          xa[u] = x[c2[u].x];
+          xb[u] = x[q + 1 < n ? c2[u].y : c2[u].x]; // (the entry behind an odd block's last one is not ours)
+        }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) {
+          const int i = 2 * (tid + u * 256);
+          if (i < n) prod[i] = v2[u].x * xa[u];
+          if (i + 1 < n) prod[i + 1] = v2[u].y * xb[u];
+        }
+      } else {
+        V v[PER];
+        int c[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+          const int q = min(tid + u * 256, max(n, 1) - 1);
+          v[u] = __builtin_nontemporal_load(values + p0 + q);
+          c[u] = __builtin_nontemporal_load(colind + p0 + q);
+        }
+#pragma unroll
+        for (int u = 0; u <= kCsrRows / 256; ++u)
+          if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
+        V xx[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) xx[u] = x[c[u]];
+#pragma unroll
+        for (int u = 0; u < PER; ++u)
+          if (tid + u * 256 < n) prod[tid + u * 256] = v[u] * xx[u];
       }
-#pragma unroll
-      for (int u = 0; u <= kCsrRows / 256; ++u)
-        if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
-      V xx[PER];
-#pragma unroll
-      for (int u = 0; u < PER; ++u) xx[u] = x[c[u]];
-#pragma unroll
-      for (int u = 0; u < PER; ++u)
-        if (tid + u * 256 < n) prod[tid + u * 256] = v[u] * xx[u];
       __syncthreads();
       // 4 lanes per row, rows strided over the workgroup
       const int sub = tid & 3;
@@ -814,8 +853,8 @@ __global__ void __launch_bounds__(256)
 // MEASURED when it is created (five SpMVs each): on the Flan stand-in they are within 5 % of
 // each other and the order changes from box to box (block / wave: 279 / 297 us on one,
 // 296 / 281 us on another).  (Reference: cpu_mv, csr_matrix.tpp:2683-2704.)
-constexpr int kCwNnz = 512; // products per chunk (8 per lane)
-constexpr int kCwRows = 63; // rows per chunk (row pointers: one per lane, + the end)
+constexpr int kCwNnz = 1024; // products per chunk (16 per lane: 12 KiB of loads in flight per wave)
+constexpr int kCwRows = 63;  // rows per chunk (row pointers: one per lane, + the end)
 template <typename V>
 __global__ void __launch_bounds__(256)
     cfs_csr_wave_kernel(const int4 *__restrict__ cd, int nchunks, const int32_t *__restrict__ rowptr,
@@ -829,7 +868,9 @@ __global__ void __launch_bounds__(256)
   const int nw = gridDim.x * 4;
   int k = blockIdx.x * 4 + w;
   if (k >= nchunks) return;
-  int4 dn = cd[k]; // {first row, rows, first nonzero, nonzeros}
+  // descriptors {first row, rows, first nonzero, nonzeros} are scalar loads issued TWO chunks
+  // ahead: the loads of the next chunk never wait for their descriptor
+  int4 dn = cd[k], dnn = cd[min(k + nw, nchunks - 1)];
   V vn[PER];
   int cn[PER], rpn;
   auto fetch = [&](const int4 &dsc) {
@@ -850,7 +891,8 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < PER; ++u) v[u] = vn[u], c[u] = cn[u];
     const int rp = rpn;
     const int kn = k + nw;
-    dn = cd[min(kn, nchunks - 1)]; // (the last chunk once more at the end of a wave's walk: unconditional loads)
+    dn = dnn; // (the last chunk once more at the end of a wave's walk: unconditional loads)
+    dnn = cd[min(kn + nw, nchunks - 1)];
     fetch(dn);
     V xx[PER];
 #pragma unroll
@@ -1045,6 +1087,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   bool has_value_map = false;
   int64_t nnz_caller = 0; // entries of the caller's CSR the maps point into
   DevBuf fold_rec, fold_idx, send_ptr, send_idx;
+  DevBuf slot_exp; // deterministic build: scale exponent of every slot
+  const short *dev_slot_exp = nullptr;
   DevBuf rfold_rec, rfold_idx;
   SymDev<V> dev{};
   int nfold = 0, nsend = 0, nrfold = 0;
@@ -1099,6 +1143,10 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     }
     UP(send_ptr, P.send_ptr)
     UP(send_idx, P.send_idx)
+    if (P.deterministic) {
+      UP(slot_exp, P.slot_exp)
+      dev_slot_exp = (const short *)slot_exp.p;
+    }
 #undef UP
     if ((rc = finish_setup((int64_t)P.slice_meta.size()))) return rc;
     // release the big host arrays; keep the small metadata
@@ -1181,7 +1229,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     dev.strip = (V *)strip.p;
     dev.row_begin = P.row_begin;
     dev.lds_slots = P.lds_slots;
-    lds_bytes = (size_t)P.lds_slots * (sizeof(V) + (P.deterministic ? 16 : 8));
+    lds_bytes = (size_t)P.lds_slots * (size_t)cfs_plan::slot_lds_bytes<V>(P.deterministic);
     // the stream is cacheable across SpMVs only if it fits the 256 MiB Infinity Cache
     nt_stream = (stream_len * (int64_t)sizeof(V) + slot_len * 2) > (int64_t)240 * 1024 * 1024;
     return 0;
@@ -1191,7 +1239,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
   template <int BLOCK> static const void *pick_kernel(int mode, bool nt, bool offb, int u, bool det, bool comb) {
 #define CFS_K(M, N, O, UU) ((const void *)cfs_sym_tile_kernel<V, BLOCK, M, N, O, UU>)
 #define CFS_KP(N, O, UU) ((const void *)cfs_sym_tile_kernel<V, BLOCK, 0, N, O, UU, false, false>)
-#define CFS_KDET(N, O, UU) ((const void *)cfs_sym_tile_kernel<V, 512, 0, N, O, UU, true>)
+#define CFS_KDET(N, O, UU) ((const void *)cfs_sym_tile_kernel<V, (BLOCK < 512 ? 512 : BLOCK), 0, N, O, UU, true>)
     constexpr int UM = cfs_plan::kSlotsPerThread;
     switch (mode) {
     case 1: return CFS_K(1, true, false, UM);
@@ -1200,7 +1248,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     case 4: return CFS_K(4, true, false, UM);
     default: break;
     }
-    if (det) { // CFS_HIP_FLAG_DETERMINISTIC: 512 threads only (to_opts)
+    if (det) { // CFS_HIP_FLAG_DETERMINISTIC: 512 or 1 024 threads (to_opts)
       static const void *const dtab[2][2][3] = {
           {{CFS_KDET(false, false, 3), CFS_KDET(false, false, 6), CFS_KDET(false, false, UM)},
            {CFS_KDET(false, true, 3), CFS_KDET(false, true, 6), CFS_KDET(false, true, UM)}},
@@ -1229,7 +1277,8 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     case 256: return pick_kernel<256>(ablate_mode, nt_stream, offblock, u, false, combine);
     case 512: return pick_kernel<512>(P.deterministic ? 0 : ablate_mode, nt_stream, offblock, u,
                                       P.deterministic, combine);
-    default: return pick_kernel<1024>(ablate_mode, nt_stream, offblock, u, false, combine);
+    default: return pick_kernel<1024>(P.deterministic ? 0 : ablate_mode, nt_stream, offblock, u, P.deterministic,
+                                      combine);
     }
   }
   int launch_tiles(V *y, const V *x, hipStream_t st) {
@@ -1243,7 +1292,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
                     (void *)&dev.cvals, (void *)&dev.crows, (void *)&dev.ccols,
                     (void *)&dev.fvals, (void *)&dev.frows, (void *)&dev.fcols,
                     (void *)&dev.strip, (void *)&dev.row_begin, (void *)&dev.lds_slots,
-                    (void *)&x, (void *)&y, (void *)&dbg_buf};
+                    (void *)&x, (void *)&y, (void *)&dbg_buf, (void *)&dev_slot_exp};
     HIPCHK(hipLaunchKernel(k, dim3(P.ngroups), dim3(P.block_threads), args, lds_bytes, st));
     return 0;
   }
@@ -1410,6 +1459,7 @@ struct cfs_hip_csr_s {
   DevBuf chunks, longrows; // wave-stream form: chunk descriptors, rows longer than a chunk
   int nchunks = 0, nlong = 0, wave_grid = 0, block_grid = 256 * 8;
   bool form_measured = false; // the faster of the two kernel forms has been chosen (first SpMV)
+  bool wide = false;          // block form: pairs of entries per lane (CFS_HIP_CSR_WIDE)
   bool block_form = false; // CFS_HIP_CSR_KERNEL=block: the workgroup-per-block kernel (A/B)
   HostStage stage;
   int device = 0;
@@ -1577,9 +1627,9 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
   if (const char *e = getenv("CFS_HIP_COST_MODEL")) r.cost_model = atoi(e) != 0;
   if (const char *e = getenv("CFS_HIP_COMBINE")) r.combine_siblings = atoi(e) != 0;
   if (const char *e = getenv("CFS_HIP_DETERMINISTIC")) r.deterministic = atoi(e) != 0;
-  if (r.deterministic) { // one kernel shape, no far entries (see YWin)
+  if (r.deterministic) { // no far entries (x[col] outside the window that sets the scale); 512 / 1 024 threads
     r.hyb = false;
-    r.block_threads = 512;
+    if (r.block_threads == 256) r.block_threads = 512;
   }
   if ((o && (o->flags & CFS_HIP_FLAG_NO_HYB)) || r.deterministic) r.hyb = false;
   r.count_far = !r.hyb && !r.deterministic &&
@@ -1605,7 +1655,8 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
 // resident wave of workgroups (a workgroup that has to wait for a slot would
 // run as a second round and double the launch time)
 template <typename V, int BLOCK> static int residency_one(size_t lds, int *nb, bool det = false) {
-  const void *k = det ? (const void *)cfs_sym_tile_kernel<V, 512, 0, true, true, cfs_plan::kSlotsPerThread, true>
+  const void *k = det ? (const void *)cfs_sym_tile_kernel<V, (BLOCK < 512 ? 512 : BLOCK), 0, true, true,
+                                                          cfs_plan::kSlotsPerThread, true>
                       : (const void *)cfs_sym_tile_kernel<V, BLOCK, 0, true, true, cfs_plan::kSlotsPerThread>;
   int dev = 0;
   HIPCHK(hipGetDevice(&dev));
@@ -1618,13 +1669,13 @@ template <typename V> static int query_residency(cfs_plan::Options &po) {
   // the window the plan builder will allow (same rule: cfs_plan::chunk_layout)
   const cfs_plan::ChunkLayout L = cfs_plan::chunk_layout<V>(1 << 30, po);
   const int block = L.block;
-  const int slot_bytes = (int)sizeof(V) + (po.deterministic ? 16 : 8);
+  const int slot_bytes = cfs_plan::slot_lds_bytes<V>(po.deterministic);
   const size_t lds = (size_t)((L.max_slots + 63) / 64 * 64) * slot_bytes;
   int nb = 0, rc;
   switch (block) {
   case 256: rc = residency_one<V, 256>(lds, &nb); break;
   case 512: rc = residency_one<V, 512>(lds, &nb, po.deterministic); break;
-  case 1024: rc = residency_one<V, 1024>(lds, &nb); break;
+  case 1024: rc = residency_one<V, 1024>(lds, &nb, po.deterministic); break;
   default: return 0; // build_plan reports the bad block size
   }
   if (rc) return rc;
@@ -2878,6 +2929,7 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     m->wave_grid = std::max(1, std::min((m->nchunks + 3) / 4, prop.multiProcessorCount * nb));
     m->block_form = true;
     m->form_measured = false;
+    if (const char *e = getenv("CFS_HIP_CSR_WIDE")) m->wide = atoi(e) != 0;
     if (const char *e = getenv("CFS_HIP_CSR_KERNEL")) { // block | wave: no measurement
       m->block_form = strcmp(e, "wave") != 0;
       m->form_measured = true;
@@ -2952,16 +3004,18 @@ static int csr_launch(cfs_hip_csr_t h, void *y, const void *x, hipStream_t st) {
     }
   } else if (h->nblocks > 0) {
     const int grid = h->nblocks < 256 * 8 ? h->nblocks : 256 * 8;
-    if (h->value_bytes == 8)
-      hipLaunchKernelGGL((cfs_csr_stream_kernel<double>), dim3(grid), dim3(256), 0, st,
-                         (const int32_t *)h->blk_row.p, h->nblocks, (const int32_t *)h->rowptr.p,
-                         (const int32_t *)h->colind.p, (const double *)h->values.p,
-                         (const double *)x, (double *)y);
-    else
-      hipLaunchKernelGGL((cfs_csr_stream_kernel<float>), dim3(grid), dim3(256), 0, st,
-                         (const int32_t *)h->blk_row.p, h->nblocks, (const int32_t *)h->rowptr.p,
-                         (const int32_t *)h->colind.p, (const float *)h->values.p,
-                         (const float *)x, (float *)y);
+#define CFS_CSR_BLOCK(V, W)                                                                              \
+  hipLaunchKernelGGL((cfs_csr_stream_kernel<V, W>), dim3(grid), dim3(256), 0, st, (const int32_t *)h->blk_row.p, \
+                     h->nblocks, (const int32_t *)h->rowptr.p, (const int32_t *)h->colind.p,                \
+                     (const V *)h->values.p, (const V *)x, (V *)y)
+    if (h->value_bytes == 8) {
+      if (h->wide) CFS_CSR_BLOCK(double, true);
+      else CFS_CSR_BLOCK(double, false);
+    } else {
+      if (h->wide) CFS_CSR_BLOCK(float, true);
+      else CFS_CSR_BLOCK(float, false);
+    }
+#undef CFS_CSR_BLOCK
   }
   HIPCHK(hipGetLastError());
   return 0;

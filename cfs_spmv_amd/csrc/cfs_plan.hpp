@@ -88,6 +88,10 @@ struct Options {
   // bit-reproducible results: the y window takes two 8-byte integer words per slot
   // (fixed-point sums, integer LDS atomics) instead of one fp64 word; no far entries
   bool deterministic = false;
+  // deterministic build: per ORIGINAL row an exponent e with 2^e > its 1-norm sum_j |a_ij| (the
+  // whole row, both triangles): the scale of the fixed-point sums of that row's slot, so that
+  // their precision does not depend on how the matrix is scaled.  Set by build_plan.
+  const int16_t *row_exp = nullptr;
   // also record, for every stored value of the device format, its position in the caller's
   // CSR value array: new values of the same sparsity pattern can then be poured into the
   // existing schedule by a device kernel (cfs_hip_sym_update_values_*) instead of tune()
@@ -134,6 +138,7 @@ constexpr int kDefaultSlots = 4992;    // 2 workgroups x (4992 x 16 B + 16 B) fi
 constexpr int kDefaultBlock = 512;    // 8 waves per workgroup, 16 per CU (measured best)
 constexpr int kStaticLds = 16;        // slice ticket counter
 constexpr int kAexpNonFinite = 30000; // Tile::aexp of a tile that holds a NaN / Inf value
+constexpr int16_t kExpNonFinite = 32000; // SymPlan::slot_exp of a row that holds a NaN / Inf value
 constexpr int kSlotsPerThread = 10;   // LDS slots one thread fills/flushes (registers)
 constexpr int kStreamPad = 256;       // padding entries behind the value / slot streams (one packet)
 
@@ -227,6 +232,7 @@ template <typename V> struct SymPlan {
                                     // every XCD's run of ngroups / 8 slots
   std::vector<int32_t> halo_col;    // [H] column of every halo slot (schedule space)
   std::vector<int32_t> slot_col;    // [sum nslots + 1] ORIGINAL column of every slot
+  std::vector<int16_t> slot_exp;    // deterministic build: [sum nslots + 1] exponent bound of the slot's row sums
   std::vector<int32_t> perm;        // [rows] schedule row -> original row (empty = identity)
   std::vector<int32_t> fold_dst;    // [F] fold destination, original local row index
   std::vector<uint32_t> rowinfo;    // [nvrows] virtual row -> local_row | npackets<<16
@@ -367,10 +373,14 @@ struct ChunkLayout {
     return c;
   }
 };
+// LDS bytes of one slot: x window in V, y window always fp64 -- two integer words and a 16-bit
+// scale exponent in the deterministic build
+template <typename V> inline int slot_lds_bytes(bool deterministic) {
+  return (int)sizeof(V) + (deterministic ? 18 : 8);
+}
 template <typename V> inline ChunkLayout chunk_layout(int rows, const Options &opt) {
   ChunkLayout L;
-  // x window in V, y window always fp64 (two integer words in the deterministic build)
-  const int slot_bytes = (int)sizeof(V) + (opt.deterministic ? 16 : 8);
+  const int slot_bytes = slot_lds_bytes<V>(opt.deterministic);
   L.block = opt.block_threads > 0 ? opt.block_threads : kDefaultBlock;
   int max_slots = opt.max_slots > 0 ? opt.max_slots : kDefaultSlots;
   if (opt.deterministic && opt.max_slots <= 0) // still two workgroups per CU
@@ -1333,6 +1343,10 @@ template <typename V> struct Builder {
       for (int h = 0; h < t.nslots - t.nown; h++)
         P.slot_col[t.slot_off + t.nown + h] = orig(P.halo_col[t.halo_off + h]);
     }
+    if (opt.deterministic && opt.row_exp) { // scale of every slot's fixed-point sums
+      P.slot_exp.assign(P.slot_col.size(), 0);
+      for (size_t q = 0; q + 1 < P.slot_col.size(); q++) P.slot_exp[q] = opt.row_exp[P.slot_col[q]];
+    }
     P.fold_dst.resize(P.fold_row.size());
     for (size_t i = 0; i < P.fold_row.size(); i++) P.fold_dst[i] = orig(P.fold_row[i] + rb) - rb;
     if (perm_in) P.perm = *perm_in;
@@ -1659,8 +1673,20 @@ template <typename V> struct ScheduleSpace {
 // CSR.  Returns false (plan.error set) when the matrix cannot be scheduled.
 template <typename V>
 bool build_plan(int n, const int *rowptr, const int *colind, const V *values, int nranks,
-                int rank, const int *row_splits_in, const Options &opt, SymPlan<V> &P,
+                int rank, const int *row_splits_in, const Options &opt_in, SymPlan<V> &P,
                 ScheduleSpace<V> *cache = nullptr) {
+  Options opt = opt_in;
+  std::vector<int16_t> row_exp;
+  if (opt.deterministic && n > 0 && rowptr && values) { // 2^e > 1-norm of every row (both triangles)
+    row_exp.assign((size_t)n, (int16_t)-1000);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+    for (int i = 0; i < n; i++) {
+      double sum = 0.0;
+      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) sum += std::fabs((double)values[j]);
+      row_exp[i] = !std::isfinite(sum) ? kExpNonFinite : (sum > 0.0 ? (int16_t)(std::ilogb(sum) + 1) : (int16_t)-1000);
+    }
+    opt.row_exp = row_exp.data();
+  }
   const int rb = row_splits_in ? row_splits_in[rank] : 0;
   const int re = row_splits_in ? row_splits_in[rank + 1] : n;
   const int rows = re - rb;

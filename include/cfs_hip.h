@@ -131,11 +131,14 @@ typedef struct {
  * tile meet in LDS through floating-point atomics, whose order varies from run to
  * run: results agree to ~1e-13 of the row scale, not bitwise (the reference adds in a
  * fixed order, csr_matrix.tpp:3005-3013).  With this flag every contribution is
- * converted to a fixed-point number (2 x 40 bits below a per-tile scale derived from
- * max|a| and max|x|) and accumulated with INTEGER LDS atomics -- associative, hence
- * the same bits whatever the order; the halo fold already adds in a fixed order.
- * Costs LDS (24 instead of 16 bytes per slot: smaller tiles) and ALU; no far entries,
- * 512-thread workgroups only.  Same tolerance against the oracle as the default.   */
+ * converted to a fixed-point number (2 x 40 bits below a PER-SLOT scale: the 1-norm of
+ * the slot's matrix row times the largest |x| of the tile's window, a bound of every
+ * partial sum) and accumulated with INTEGER LDS atomics -- associative, hence the same
+ * bits whatever the order; the halo fold already adds in a fixed order.  The precision
+ * does not depend on how the matrix is scaled.  Costs LDS (26 instead of 16 bytes per
+ * slot: smaller tiles) and ALU; 512- or 1 024-thread workgroups; no far entries (their x
+ * lies outside the window that sets the scale).  A NaN / Inf in x or in the matrix reads
+ * NaN in the rows it reaches.  Same tolerance against the oracle as the default.   */
 #define CFS_HIP_FLAG_DETERMINISTIC 1024
 /* keep, for every stored value of the device format, its position in the caller's CSR
  * value array (4 bytes per stored nonzero of device memory): cfs_hip_sym_update_values_*

@@ -179,6 +179,39 @@ def test_deterministic_mode_with_wide_value_range():
     M.close()
 
 
+@pytest.mark.parametrize("block", [0, 1024])
+def test_deterministic_mode_is_independent_of_row_scaling(block):
+    """per-SLOT fixed-point scales (row 1-norm x window max|x|): rows scaled 2^-30 .. 2^30 against
+    each other -- entries spread over 2^120, far beyond what one scale per tile could hold -- meet
+    the 1e-12 bound against the long-double row sums on their OWN scale, bit-reproducibly; also in
+    the 1 024-thread shape.  Reference behaviour this stands in for: the fixed
+    accumulation order of csr_matrix.tpp:3005-3013."""
+    import scipy.sparse as sp
+    import cfs_spmv_amd as cfs
+    from oracle import oracle
+    torch = _torch()
+    n = 6000
+    rng = np.random.default_rng(9)
+    L = sp.tril(sp.random(n, n, density=0.004, random_state=11, format="csr"), -1).tocsr()
+    scale = 2.0 ** rng.integers(-30, 31, size=n)
+    D = sp.diags(scale)
+    L = (D @ L @ D).tocsr()
+    A = (L + L.T + sp.diags(scale * scale)).tocsr()
+    A.sort_indices()
+    rp, ci, va = A.indptr.astype(np.int32), A.indices.astype(np.int32), A.data
+    x = rng.uniform(-1, 1, n)
+    M = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(block_threads=block, flags=FLAG_DET | FLAG_NO_CAL))
+    assert M.stats()["block_threads"] == (block or 512)
+    y = _spmv(M, x, torch)
+    y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
+    assert scaled_err(y, y_ld, absrow) <= 1e-12
+    assert np.array_equal(y.view(np.uint8), _spmv(M, x, torch).view(np.uint8))
+    M2 = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(block_threads=block, flags=FLAG_DET | FLAG_NO_CAL))
+    assert np.array_equal(y.view(np.uint8), _spmv(M2, x, torch).view(np.uint8))
+    M.close()
+    M2.close()
+
+
 @pytest.mark.parametrize("where", ["x", "a"])
 @pytest.mark.parametrize("bad", [float("nan"), float("inf")])
 def test_deterministic_mode_propagates_nan_and_inf(where, bad):

@@ -14,6 +14,8 @@ for arg in sys.argv[2:]:
     for name in ("bench.json", "kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "hbm_traffic.json"):
         shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_{name}"))
     t = json.load(open(os.path.join(src, "hbm_traffic.json")))
+    if "cfs_sym_tile_kernel" not in t:  # (a general-CSR set: no schedule to match, not in the table)
+        continue
     table.setdefault(key, []).append({
         "hbm_bytes_per_launch": t["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"],
         "kernel": "cfs_sym_tile_kernel",

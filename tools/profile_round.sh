@@ -17,7 +17,10 @@ mkdir -p $out
 python3 bench.py "$@" > $out/bench.json 2> $out/bench.err || { echo "bench failed"; tail -5 $out/bench.err; exit 1; }
 # the profiler passes run the window shape tune() kept in the bench run above (the two
 # shapes are within a few per cent of each other; under the profiler the clock may say otherwise)
-export CFS_HIP_SHAPE=$(python3 -c "import json,sys; print(json.load(open('$out/bench.json'))['config']['block_threads'])")
+export CFS_HIP_SHAPE=$(python3 -c "import json,sys; print(json.load(open('$out/bench.json'))['config'].get('block_threads', 0))")
+# ... and the general CSR form the bench run measured to be faster
+form=$(python3 -c "import json,sys; print(json.load(open('$out/bench.json'))['config'].get('kernel_form', '').split(' ')[0])")
+if [ -n "$form" ]; then export CFS_HIP_CSR_KERNEL=$form; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py --steps 100 --warmup 20 --no-cpu-baseline "$@" > $out/bench_traced.json 2> $out/trace.err
 cp $out/trace/*/*_kernel_stats.csv $out/kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pmc_f -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > /dev/null 2> $out/pmc_f.err
@@ -33,10 +36,11 @@ def mean(path, counter, kern):
     v = [float(r['Counter_Value']) for r in csv.DictReader(open(path))
          if r['Counter_Name'] == counter and kern in r['Kernel_Name']]
     return (sum(v) / len(v), len(v)) if v else (0.0, 0)
-res = {"bench_config": b["config"]["workload"][:120], "lds_bytes": b["config"]["lds_bytes"],
-       "block_threads": b["config"]["block_threads"],
-       "bytes_streamed": b["roofline"]["bytes_streamed_by_format"]}
-for kern in ("cfs_sym_tile_kernel", "cfs_fold_kernel"):
+main = b["roofline"].get("kernel", "cfs_sym_tile_kernel")
+res = {"bench_config": b["config"]["workload"][:120], "lds_bytes": b["config"].get("lds_bytes"),
+       "block_threads": b["config"].get("block_threads"),
+       "bytes_streamed": b["roofline"].get("bytes_streamed_by_format")}
+for kern in ((main, "cfs_fold_kernel") if main == "cfs_sym_tile_kernel" else (main,)):
     f, nf = mean(out + '/pmc_fetch.csv', 'FETCH_SIZE', kern)
     w, nw = mean(out + '/pmc_write.csv', 'WRITE_SIZE', kern)
     res[kern] = {"FETCH_SIZE_KiB_raw": f, "WRITE_SIZE_KiB": w, "launches": [nf, nw],
@@ -50,12 +54,12 @@ for name in ('pmc_fetch.csv', 'pmc_write.csv'):
     with open(out + '/' + name, 'w', newline='') as fo:
         w = csv.DictWriter(fo, fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep[:400])
 ks = [r for r in csv.DictReader(open(out + '/kernel_stats.csv'))]
-t = [r for r in ks if 'cfs_sym_tile_kernel' in r['Name']]
+t = [r for r in ks if main in r['Name']]
 prod = max(t, key=lambda r: int(r['Calls']))  # the instantiation of the timed steps (not tune()'s trials)
 avg = float(prod['TotalDurationNs']) / int(prod['Calls'])
 print(json.dumps({"tag": out, "ms_per_step": b["ms_per_step"], "value": b["value"],
                   "kernel_ms_events": b["roofline"]["kernel_ms"], "kernel_ms_rocprof": round(avg * 1e-6, 5),
-                  "frac": b["roofline"]["frac"], "hbm_bytes_tile": res["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"],
+                  "frac": b["roofline"]["frac"], "hbm_bytes_tile": res[main]["hbm_bytes_per_launch"],
                   "alg_bytes": b["roofline"]["algorithmic_bytes_per_launch"], "preproc_s": b["config"]["preproc_s"],
                   "cpu": b.get("cpu_baseline", {}).get("value")}))
 PY
