@@ -79,6 +79,9 @@ def parse():
     ap.add_argument("--format", default="sss", choices=["sss", "csr"],
                     help="sss (default): the symmetric hot path.  csr: Format::csr -- every stored entry "
                          "through the general CSR kernel (cpu_mv's role, csr_matrix.tpp:2683-2704), N = 1")
+    ap.add_argument("--settle-ms", type=float, default=300.0,
+                    help="untimed SpMVs before the W warm-up steps (set-up: clocks and power in the state "
+                         "of a long run)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the tile kernel with HIP events on every n-th timed step")
     return ap.parse_args()
@@ -196,7 +199,7 @@ def bench_csr(args, cfs, lib, n, rp, ci, va, x_host, nnz_full, dev, t_dt, data_k
     ev0 = {i: new_event() for i in sampled}
     ev1 = {i: new_event() for i in sampled}
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.030:
+    while time.perf_counter() - t_pre < args.settle_ms * 1e-3:
         for _ in range(16):
             step()
         torch.cuda.synchronize()
@@ -539,11 +542,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # set-up, untimed: bring clocks and caches to the state of a long run before the W
-    # warm-up steps (a run with --warmup 5 would otherwise time the clock ramp: the same
-    # binary reads 5 % slower).  At least 30 ms of SpMVs, ending idle.
+    # set-up, untimed: bring clocks, power state and caches to the state of a long run before
+    # the W warm-up steps.  Two transients were measured on MI355X: the clock ramp of an idle
+    # GPU (a run with --warmup 5 alone read 5 % slow), and ~0.2 s of reduced clocks right after
+    # the burst of tune()'s device kernels (radix sorts over 60 M keys): with 30 ms of set-up a
+    # device-built schedule read 4-5 % slower than the bit-identical host-built one over 200
+    # steps and equal (0.5 %) over 4 000 (profiles/r03_experiment_notes.md).  --settle-ms of
+    # SpMVs (default 300), ending idle.
     t_pre = time.perf_counter()
-    while time.perf_counter() - t_pre < 0.030:
+    while time.perf_counter() - t_pre < args.settle_ms * 1e-3:
         for _ in range(32):
             step()
         torch.cuda.synchronize()

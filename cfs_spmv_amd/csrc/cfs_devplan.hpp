@@ -792,6 +792,18 @@ struct Sched {
   DevBuf keys, keys2, kv, kv2;
   DevBuf brp, bci, dsrc, lcnt, firstcol;
   const int32_t *bsrc() const { return (const int32_t *)kv2.p; }
+  // the big arrays of a placement (first-time device allocations of this size take tens of
+  // milliseconds: build() reserves them on a thread of its own while the host clusters)
+  int reserve(long long nl_, int rows_) {
+    const size_t nl = (size_t)nl_;
+    int rc;
+    if ((rc = keys.alloc((nl + 1) * 8)) || (rc = keys2.alloc((nl + 1) * 8)) || (rc = kv.alloc((nl + 1) * 4)) ||
+        (rc = kv2.alloc((nl + 1) * 4)) || (rc = dsrc.alloc((size_t)rows_ * 4 + 4)) ||
+        (rc = brp.alloc(((size_t)rows_ + 2) * 4)) || (rc = bci.alloc((nl + 1) * 4)) ||
+        (rc = lcnt.alloc((size_t)rows_ * 4 + 4)) || (rc = firstcol.alloc((size_t)rows_ * 4 + 4)))
+      return rc;
+    return 0;
+  }
   std::vector<int32_t> h_lcnt, chunk;
   std::vector<int64_t> cost;
   std::vector<Tile> tiles;
@@ -810,8 +822,7 @@ template <typename V> struct Input {
 // positions of the entries with col <= row (binary search: columns ascend -- verified on the
 // device against the real counts), compact value array, uploads
 template <typename V>
-int upload_input(int n, const int *rowptr, const int *colind, const V *values, int rb, int re, bool mirror,
-                 Input<V> &in) {
+void scan_input(int n, const int *rowptr, const int *colind, int rb, int re, bool mirror, Input<V> &in) {
   in.n = n;
   in.row_lo = rb;
   in.row_hi = mirror ? n : re;
@@ -833,6 +844,9 @@ int upload_input(int n, const int *rowptr, const int *colind, const V *values, i
   in.nl = in.h_lrp[nr];
   in.nnz_low = low;
   in.nnz_diag = dg;
+}
+template <typename V>
+int upload_input(int n, const int *rowptr, const int *colind, const V *values, Input<V> &in) {
   int rc;
   if ((rc = in.rowptr.upload(rowptr, ((size_t)n + 1) * 4))) return rc;
   if ((rc = in.colind.upload(colind, (size_t)rowptr[n] * 4))) return rc;
@@ -891,11 +905,8 @@ int place(const Input<V> &in, int rb, int re, bool mirror, const std::vector<int
     if ((rc = S.perm.upload(perm_h->data(), perm_h->size() * 4))) return rc;
   }
   const size_t nl = (size_t)in.nl;
-  if ((rc = S.keys.alloc((nl + 1) * 8)) || (rc = S.keys2.alloc((nl + 1) * 8)) || (rc = S.kv.alloc((nl + 1) * 4)) ||
-      (rc = S.kv2.alloc((nl + 1) * 4)) || (rc = S.dsrc.alloc((size_t)rows * 4 + 4)) ||
-      (rc = S.brp.alloc(((size_t)rows + 2) * 4)) || (rc = S.bci.alloc((nl + 1) * 4)) ||
-      (rc = S.lcnt.alloc((size_t)rows * 4 + 4)) || (rc = S.firstcol.alloc((size_t)rows * 4 + 4)))
-    return rc;
+  if (!S.keys.p || S.keys.bytes < (nl + 1) * 8 || !S.firstcol.p) // (not reserved ahead)
+    if ((rc = S.reserve(in.nl, rows))) return rc;
   pt.lap("  place: inverse order, buffers");
   HIPCHK(hipMemsetAsync(S.dsrc.p, 0xff, (size_t)rows * 4 + 4, 0));
   HIPCHK(hipMemsetAsync(ctr.p, 0, C_COUNT * 8, 0));
@@ -1075,9 +1086,10 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   int up_rc = 0, cur_dev = 0;
   std::string up_err;
   HIPCHK(hipGetDevice(&cur_dev));
+  scan_input<V>(n, rowptr, colind, rb, re, mirror, in); // row prefixes col <= row (binary searches)
   auto do_upload = [&]() {
     (void)hipSetDevice(cur_dev);
-    up_rc = upload_input<V>(n, rowptr, colind, values, rb, re, mirror, in);
+    up_rc = upload_input<V>(n, rowptr, colind, values, in);
     if (up_rc) up_err = cfs_rt::last_error(); // (the message is thread-local)
   };
   std::thread uploader;
@@ -1088,15 +1100,27 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   } catch (...) {
     do_upload();
   }
-  struct Joiner { // every return path waits for the upload thread
+  struct Joiner { // every return path waits for the helper threads
     std::thread &t;
     ~Joiner() {
       if (t.joinable()) t.join();
     }
   } joiner{uploader};
+  // ... and so does the first-time allocation of the placement's arrays (~50 ms for 2.3 GB)
+  Sched SC, SN, *S = nullptr;
+  const bool may_cluster = opt.reorder && opt.force_order != 1 && rows >= 256;
+  int res_rc = 0;
+  std::thread reserver;
+  try {
+    reserver = std::thread([&]() {
+      (void)hipSetDevice(cur_dev);
+      res_rc = (may_cluster ? SC : SN).reserve(in.nl, rows); // the order that is placed first
+    });
+  } catch (...) {
+  }
+  Joiner joiner2{reserver};
 
   // ---- row order: natural, or the clusters of the host's graph-growing sweep -------------------
-  const bool may_cluster = opt.reorder && opt.force_order != 1 && rows >= 256;
   std::vector<int32_t> perm, cchunk;
   bool have_clusters = false;
   if (may_cluster) {
@@ -1121,9 +1145,10 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     }
   }
   if (threaded) uploader.join();
+  if (reserver.joinable()) reserver.join();
   if (up_rc) return set_err(up_rc, up_err);
+  if (res_rc) return res_rc;
   pt.lap("device: upload CSR || cluster_rows (host)");
-  Sched SC, SN, *S = nullptr;
   bool use_clustered = have_clusters;
   const bool reused = have_clusters && cache && cache->valid && cache->nchunks == 2 * nc;
   auto natural_chunks = [&](Sched &X) { // cfs_plan::Builder::cut_chunks
@@ -1281,8 +1306,9 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   const size_t vlen = (size_t)off + kStreamPad, slen = (size_t)soff + kStreamPad, clen = (size_t)coo + 256;
   if ((rc = halo_col.alloc(((size_t)halo + 1) * 4)) || (rc = val_map.alloc(vlen * 4)) ||
       (rc = cval_map.alloc(clen * 4)) || (rc = diag_map.alloc(((size_t)nvr + 1) * 4)) ||
-      (rc = m.slots.alloc(slen * 2)) || (rc = m.crows.alloc(clen * 2)) || (rc = m.ccols.alloc(clen * 2)))
+      (rc = m.crows.alloc(clen * 2)) || (rc = m.ccols.alloc(clen * 2)))
     return rc;
+  if ((rc = m.slots.alloc(slen * 2))) return rc;
   HIPCHK(hipMemsetAsync(halo_col.p, 0, ((size_t)halo + 1) * 4, 0));
   HIPCHK(hipMemsetAsync(val_map.p, 0xff, vlen * 4, 0));
   HIPCHK(hipMemsetAsync(cval_map.p, 0xff, clen * 4, 0));
@@ -1489,9 +1515,8 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   // hand the remaining arrays over
   m.tiles = std::move(d_tiles);
   m.tiles.bytes = (size_t)T * sizeof(Tile);
-  if ((rc = m.adopt_device_schedule())) return rc;
   pt.lap("device: metadata");
-  return 0;
+  return 0; // (the caller adopts the schedule once this function's temporaries are gone)
 }
 
 } // namespace cfs_dev

@@ -1232,6 +1232,11 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
     lds_bytes = (size_t)P.lds_slots * (size_t)cfs_plan::slot_lds_bytes<V>(P.deterministic);
     // the stream is cacheable across SpMVs only if it fits the 256 MiB Infinity Cache
     nt_stream = (stream_len * (int64_t)sizeof(V) + slot_len * 2) > (int64_t)240 * 1024 * 1024;
+    if (getenv("CFS_PLAN_VERBOSE"))
+      fprintf(stderr, "[cfs_hip] handle: %s-built, %d tiles, window %d slots, %d threads x %d per CU, sibling chains %lld of %lld "
+              "lane-packets -> %s kernel, %s stream loads\n", device_built ? "device" : "host", (int)P.tiles.size(),
+              P.lds_slots, P.block_threads, P.wg_per_cu, (long long)P.chained_packets, (long long)P.lane_packets,
+              combine ? "combining" : "plain", nt_stream ? "non-temporal" : "cacheable");
     return 0;
   }
 
@@ -1726,7 +1731,7 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
       std::string why;
       const int r2 = cfs_dev::build<V>(n, rowptr, colind, values, nranks, rank,
                                        nranks > 1 ? row_splits : nullptr, o, *h, sp, why);
-      if (r2 == 0) return 0;
+      if (r2 == 0) return h->adopt_device_schedule(); // (the builder's temporaries are gone by now)
       if (r2 < 0) return r2;
       if (getenv("CFS_PLAN_VERBOSE")) fprintf(stderr, "[cfs_hip] device builder hands over: %s\n", why.c_str());
       h->device_built = false;
@@ -2929,6 +2934,7 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     m->wave_grid = std::max(1, std::min((m->nchunks + 3) / 4, prop.multiProcessorCount * nb));
     m->block_form = true;
     m->form_measured = false;
+    m->wide = true; // pairs of entries per lane: Flan stand-in 275-289 us against 284-294, ldoor even
     if (const char *e = getenv("CFS_HIP_CSR_WIDE")) m->wide = atoi(e) != 0;
     if (const char *e = getenv("CFS_HIP_CSR_KERNEL")) { // block | wave: no measurement
       m->block_form = strcmp(e, "wave") != 0;

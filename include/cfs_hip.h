@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CFS_HIP_ABI_VERSION 3
+#define CFS_HIP_ABI_VERSION 4
 
 /* error codes */
 #define CFS_HIP_OK 0

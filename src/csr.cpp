@@ -144,6 +144,57 @@ bool CSRMatrix<IndexT, ValueT>::tune(Kernel, Tuning t) {
       sym_handle_ = h;
     }
   }
+  // Tuning::Aggressive, one GPU: where the symmetric schedule may not pay -- a matrix without
+  // locality (power-law graphs: hub columns make nearly every column of a tile a halo slot or a
+  // far entry; profiles/r03_powerlaw_*: 3.6 x the algorithmic bytes cross the HBM interface) --
+  // the general CSR kernel over both triangles is MEASURED against it on the caller's matrix and
+  // the faster one is kept.  Candidates: halo slots + far entries beyond a quarter of the stored
+  // nonzeros (FEM-like matrices: 1-5 %).  Reference knob of the kind: the format argument of
+  // create() (sparse_matrix.tpp:13-24) -- here the measured choice inside Format::sss.
+  if (use_sss && t == Tuning::Aggressive && cfs::util::runtime::get_num_gpus() == 1 &&
+      getenv("CFS_NO_FORMAT_CHOICE") == nullptr) {
+    cfs_hip_sym_stats st;
+    cfs_hip_sym_get_stats((cfs_hip_sym_t)sym_handle_, &st);
+    if ((st.halo_slots + st.far_entries) * 4 > st.nnz_low && st.nnz_low >= 100000) {
+      cfs_hip_csr_t g = nullptr;
+      if (std::is_same<ValueT, double>::value)
+        rc = cfs_hip_csr_create_f64(nrows_, ncols_, rowptr_, colind_, (const double *)values_, &g);
+      else
+        rc = cfs_hip_csr_create_f32(nrows_, ncols_, rowptr_, colind_, (const float *)values_, &g);
+      void *xd = nullptr, *yd = nullptr, *e0 = nullptr, *e1 = nullptr;
+      float ms_sym = 0, ms_csr = 0;
+      bool ok = rc == 0 && cfs_hip_alloc((size_t)ncols_ * sizeof(ValueT), CFS_HIP_MEM_DEVICE, &xd) == 0 &&
+                cfs_hip_alloc((size_t)nrows_ * sizeof(ValueT), CFS_HIP_MEM_DEVICE, &yd) == 0 &&
+                cfs_hip_memset(xd, 0x3f, (size_t)ncols_ * sizeof(ValueT)) == 0 && // small positive values
+                cfs_hip_event_create(&e0) == 0 && cfs_hip_event_create(&e1) == 0;
+      for (int which = 0; ok && which < 2; which++) {
+        auto run = [&]() {
+          return which == 0 ? cfs_hip_sym_spmv_async((cfs_hip_sym_t)sym_handle_, yd, xd, nullptr)
+                            : cfs_hip_csr_spmv_async(g, yd, xd, nullptr);
+        };
+        for (int it = 0; ok && it < 3; it++) ok = run() == 0; // (the CSR handle picks its kernel form here)
+        ok = ok && cfs_hip_event_record(e0, nullptr) == 0;
+        for (int it = 0; ok && it < 5; it++) ok = run() == 0;
+        ok = ok && cfs_hip_event_record(e1, nullptr) == 0 &&
+             cfs_hip_event_elapsed_ms(e0, e1, which == 0 ? &ms_sym : &ms_csr) == 0;
+      }
+      if (e0) cfs_hip_event_destroy(e0);
+      if (e1) cfs_hip_event_destroy(e1);
+      if (xd) cfs_hip_free(xd, CFS_HIP_MEM_DEVICE);
+      if (yd) cfs_hip_free(yd, CFS_HIP_MEM_DEVICE);
+      if (ok && ms_csr < 0.9f * ms_sym) { // the general kernel wins clearly: keep it
+        std::cout << "[INFO]: symmetric tile schedule " << ms_sym / 5 * 1e3 << " us per SpMV, general CSR kernel "
+                  << ms_csr / 5 * 1e3 << " us: no locality to exploit -- using the general CSR kernel" << std::endl;
+        cfs_hip_sym_destroy((cfs_hip_sym_t)sym_handle_);
+        sym_handle_ = nullptr;
+        csr_handle_ = g;
+        device_bytes_ = ((size_t)nrows_ + 1) * sizeof(IndexT) + (size_t)nnz_ * (sizeof(IndexT) + sizeof(ValueT));
+        tuned_ = true;
+        return true;
+      }
+      if (g) cfs_hip_csr_destroy(g);
+    }
+  }
   if (use_sss) {
     cfs_hip_sym_stats st;
     cfs_hip_sym_get_stats((cfs_hip_sym_t)sym_handle_, &st);

@@ -22,7 +22,7 @@ def header_symbols():
 
 def test_library_loads_and_exports_every_declared_symbol():
     lib = cfs.load()
-    assert lib.cfs_hip_abi_version() == 3
+    assert lib.cfs_hip_abi_version() == 4
     syms = header_symbols()
     assert len(syms) >= 30
     for name in syms:

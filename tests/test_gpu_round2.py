@@ -308,6 +308,29 @@ def test_cxx_driver_with_cfs_num_gpus(tmp_path):
     assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout + r.stderr
 
 
+def test_tune_measures_the_general_kernel_where_the_tile_format_has_no_locality(tmp_path):
+    """CSRMatrix::tune(Aggressive) behind the unmodified self-check driver: a power-law graph
+    (hub columns: nearly every column of a tile is a halo slot or a far entry) is timed with the
+    symmetric schedule AND the general CSR kernel, the faster one kept; a mesh-like matrix never
+    takes that detour.  Either way the reference's own check passes."""
+    from cfs_spmv_amd import synth
+    env = dict(os.environ, CFS_SEED="5")
+    for name, scale, expect in (("powerlaw", 0.3, True), ("tetmesh", 0.05, False)):
+        n, rp, ci, va, _ = synth.generate(name, scale)
+        p = str(tmp_path / f"{name}.mtx")
+        synth.write_mtx(p, n, rp, ci, va)
+        r = subprocess.run([os.path.join(ROOT, "build", "test_spmv_mmf"), p, "1"],
+                           capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0 and "PASSED!" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        took_csr = "using the general CSR kernel" in r.stdout
+        assert took_csr == expect, (name, r.stdout[-1500:])
+        # ... and the choice can be switched off
+        if expect:
+            r = subprocess.run([os.path.join(ROOT, "build", "test_spmv_mmf"), p, "1"], capture_output=True,
+                               text=True, env=dict(env, CFS_NO_FORMAT_CHOICE="1"), timeout=600)
+            assert r.returncode == 0 and "PASSED!" in r.stdout and "general CSR kernel" not in r.stdout
+
+
 def test_host_pointer_path_uses_the_pinned_pool():
     import cfs_spmv_amd as cfs
     from cfs_spmv_amd import _lib, synth
