@@ -53,6 +53,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1650,6 +1651,7 @@ void cluster_rows(int n, const int *rowptr, const int *colind, int rb, int re, i
 template <typename V> struct ScheduleSpace {
   bool valid = false;
   bool device_only = false; // perm / chunk only: the matrix arrays live on the GPU (cfs_devplan.hpp)
+  std::shared_ptr<void> device_keep; // ... the uploaded matrix and its clustered placement (cfs_dev::Kept)
   int rb = 0, re = 0, nchunks = 0;
   std::vector<int32_t> perm, chunk, brp;
   BigVec<int32_t> bci;
@@ -1662,6 +1664,7 @@ template <typename V> struct ScheduleSpace {
   void drop() {
     valid = false;
     device_only = false;
+    device_keep.reset();
     release_async(bci);
     release_async(bva);
     release_async(bsr);

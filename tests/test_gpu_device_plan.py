@@ -70,6 +70,22 @@ def test_device_schedule_equals_host_schedule_on_stand_ins(name, scale, dtype):
     H.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_tuned_alternative_reuses_the_kept_placement(dtype, monkeypatch):
+    """Tuning::Aggressive builds a second schedule (1 024 threads x 1 per CU, half as many clusters:
+    pairs of the first schedule's) -- on the device from the KEPT upload and placement of the first
+    build (cfs_dev::Kept), on the host from its schedule-space matrix: the same schedule again"""
+    monkeypatch.setenv("CFS_HIP_SHAPE", "1024")  # keep the alternative whatever the clock says
+    n, rp, ci, va, _ = synth.generate("Flan_1565", 0.3)
+    va = va.astype(dtype)
+    D = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=16))  # clustered order
+    H = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=16 | cfs.FLAG_HOST_PLAN))
+    assert D.stats()["block_threads"] == 1024 and H.stats()["block_threads"] == 1024
+    _assert_same(D, H, ("tuned alternative", dtype.__name__))
+    D.close()
+    H.close()
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_device_schedule_equals_host_schedule_on_random_matrices(seed):
     rng = np.random.default_rng(5000 + seed)
