@@ -28,8 +28,7 @@
 // The host keeps what is sequential and small: the clustering sweep (cluster_rows), the
 // cost prefix over rows, chunk boundaries, offsets over ~500 tiles, the launch order.
 // Not covered (the host builder takes those, the same schedule either way): HYB far
-// entries, the deterministic build's per-tile exponent, the exchange form of a shard,
-// rows that are not sorted by column.
+// entries, rows that are not sorted by column or hold duplicates, rows longer than 4 096.
 #pragma once
 
 #include <hipcub/hipcub.hpp>
@@ -705,6 +704,20 @@ __global__ void __launch_bounds__(kBlock)
   }
 }
 
+// deterministic build: scale exponent of every slot = that of its (original) matrix row
+__global__ void __launch_bounds__(kBlock)
+    dp_slotexp_kernel(const int32_t *__restrict__ slot_col, const int16_t *__restrict__ row_exp, long long nsl,
+                      int16_t *__restrict__ slot_exp) {
+  const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (q < nsl) slot_exp[q] = row_exp[slot_col[q]];
+}
+__global__ void __launch_bounds__(kBlock)
+    dp_gatherkeys_kernel(const uint32_t *__restrict__ skeys, const int32_t *__restrict__ start, int m,
+                         int32_t *__restrict__ out) {
+  const int i = blockIdx.x * kBlock + threadIdx.x;
+  if (i < m) out[i] = (int32_t)skeys[start[i]];
+}
+
 // ---- halo fold index: strips -> destination rows (cfs_plan::Builder::fold_index + the records
 //      of make_fold_records) ------------------------------------------------------------------
 __global__ void __launch_bounds__(kBlock)
@@ -1070,7 +1083,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   if (rb < 0 || re > n || rb > re) return kUseHost; // the host builder reports it
   const int rows = re - rb;
   const bool mirror = opt.mirror_offblock && nranks > 1;
-  if (opt.hyb || opt.deterministic || !opt.group_share.empty() || (nranks > 1 && !mirror) || rows < 1 ||
+  if (opt.hyb || !opt.group_share.empty() || rows < 1 ||
       (opt.block_threads != 0 && opt.block_threads != 256 && opt.block_threads != 512 && opt.block_threads != 1024)) {
     why = "option not covered by the device builder";
     return kUseHost;
@@ -1379,6 +1392,18 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   hipLaunchKernelGGL(dp_slotcol_kernel, dim3(T), dim3(kBlock), 0, 0, (const Tile *)d_tiles.p, rb, re,
                      perm.empty() ? nullptr : (const int32_t *)S->perm.p, (const int32_t *)halo_col.p,
                      (int32_t *)m.slot_col.p);
+  if (opt.deterministic) { // per-slot scale exponents of the fixed-point sums (cfs_plan::compute_row_exp)
+    std::vector<int16_t> row_exp;
+    compute_row_exp<V>(n, rowptr, values, row_exp);
+    DevBuf d_rexp;
+    if ((rc = d_rexp.upload(row_exp.data(), row_exp.size() * 2)) || (rc = m.slot_exp.alloc(((size_t)nsl + 1) * 2)))
+      return rc;
+    HIPCHK(hipMemsetAsync(m.slot_exp.p, 0, ((size_t)nsl + 1) * 2, 0));
+    hipLaunchKernelGGL(dp_slotexp_kernel, dim3((unsigned)((nsl + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0,
+                       (const int32_t *)m.slot_col.p, (const int16_t *)d_rexp.p, (long long)nsl, (int16_t *)m.slot_exp.p);
+    HIPCHK(hipDeviceSynchronize()); // d_rexp goes out of scope
+    m.dev_slot_exp = (const short *)m.slot_exp.p;
+  }
   HIPCHK(hipGetLastError());
   pt.lap("device: slot tables, packets, leftovers");
 
@@ -1405,10 +1430,35 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     int32_t hb[2] = {0, 0};
     HIPCHK(hipMemcpy(hb, bounds.p, 8, hipMemcpyDeviceToHost));
     const int lo = hb[0], F = hb[1] - hb[0];
-    onesided = (long long)H - F;
-    if (!mirror && onesided != 0) {
-      why = "halo column outside the block";
+    onesided = mirror ? (long long)H - F : 0;
+    if (!mirror && hb[1] != H) {
+      why = "halo column right of the block";
       return kUseHost;
+    }
+    if (!mirror && lo > 0) { // exchange form of a shard: sums for rows of lower ranks are packed and sent
+      DevBuf sflag, spos, sstart, srow;
+      if ((rc = sflag.alloc((size_t)lo * 4 + 4)) || (rc = spos.alloc((size_t)lo * 4 + 4))) return rc;
+      hipLaunchKernelGGL(dp_foldflag_kernel, dim3((lo + kBlock - 1) / kBlock), dim3(kBlock), 0, 0,
+                         (const uint32_t *)fk2.p, 0, lo, (int32_t *)sflag.p);
+      tb = 0;
+      HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const int32_t *)sflag.p, (int32_t *)spos.p, lo, (hipStream_t)0));
+      if ((rc = tmp.need(tb))) return rc;
+      tb = tmp.buf.bytes;
+      HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.buf.p, tb, (const int32_t *)sflag.p, (int32_t *)spos.p, lo, (hipStream_t)0));
+      int32_t lp = 0, lf = 0;
+      HIPCHK(hipMemcpy(&lp, (const int32_t *)spos.p + (lo - 1), 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(&lf, (const int32_t *)sflag.p + (lo - 1), 4, hipMemcpyDeviceToHost));
+      const int ns = lp + lf;
+      if ((rc = sstart.alloc(((size_t)ns + 2) * 4)) || (rc = srow.alloc((size_t)ns * 4 + 4))) return rc;
+      hipLaunchKernelGGL(dp_foldstart_kernel, dim3((lo + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, 0,
+                         (const int32_t *)sflag.p, (const int32_t *)spos.p, lo, (int32_t *)sstart.p);
+      hipLaunchKernelGGL(dp_gatherkeys_kernel, dim3((ns + kBlock - 1) / kBlock), dim3(kBlock), 0, 0,
+                         (const uint32_t *)fk2.p, (const int32_t *)sstart.p, ns, (int32_t *)srow.p);
+      if ((rc = dl(m.P.send_ptr, sstart, (size_t)ns + 1)) || (rc = dl(m.P.send_row, srow, (size_t)ns))) return rc;
+      if ((rc = m.send_ptr.upload(m.P.send_ptr.data(), m.P.send_ptr.size() * 4)) || (rc = m.send_idx.alloc((size_t)lo * 4 + 4)))
+        return rc;
+      HIPCHK(hipMemcpy(m.send_idx.p, fv2.p, (size_t)lo * 4, hipMemcpyDeviceToDevice));
+      m.send_idx.bytes = (size_t)lo * 4;
     }
     if (F > 0) {
       DevBuf flag, pos, start, restlen, restoff;
@@ -1523,7 +1573,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   P.block_threads = L.block;
   P.wg_per_cu = L.wg_per_cu;
   P.ngroups = L.ngroups;
-  P.deterministic = false;
+  P.deterministic = opt.deterministic;
   P.mirrored = mirror;
   P.mirror_entries = S->mirror_entries;
   P.onesided_slots = onesided;
@@ -1549,6 +1599,10 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   compute_launch_order(L, opt, P.tiles, P.group_ptr, S->cost, rb, P.launch_order);
   P.fold_dst.assign((size_t)nfold, 0); // (sizes only: the records are on the device)
   P.send_counts.assign(nranks, 0);
+  for (int r : P.send_row) { // owner of every row this shard sends sums to (cfs_plan::Builder::fold_index)
+    const int owner = (int)(std::upper_bound(P.row_splits.begin(), P.row_splits.end(), r) - P.row_splits.begin()) - 1;
+    P.send_counts[owner]++;
+  }
   // hand the remaining arrays over
   m.tiles = std::move(d_tiles);
   m.tiles.bytes = (size_t)T * sizeof(Tile);

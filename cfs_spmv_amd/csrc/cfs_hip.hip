@@ -2615,6 +2615,9 @@ template <typename V> static int sym_digest(SymMatrix<V> *m, unsigned long long 
   if ((rc = dig(m->cval_map, m->has_value_map ? (size_t)m->coo_len * 4 : 0, &w[k++]))) return rc;
   if ((rc = dig(m->diag_map, m->has_value_map ? (size_t)nvr * 4 : 0, &w[k++]))) return rc;
   w[k++] = (unsigned long long)m->P.lds_slots | ((unsigned long long)m->P.ngroups << 32);
+  if ((rc = dig(m->slot_exp, m->P.deterministic ? (size_t)nsl * 2 : 0, &w[k++]))) return rc;
+  if ((rc = dig(m->send_ptr, m->nsend > 0 ? ((size_t)m->nsend + 1) * 4 : 0, &w[k++]))) return rc;
+  if ((rc = dig(m->send_idx, m->nsend > 0 ? (size_t)m->P.send_ptr.back() * 4 : 0, &w[k++]))) return rc;
   w[CFS_HIP_DIGEST_WORDS - 1] = m->device_built ? 1ull : 0ull;
   return 0;
 }

@@ -1672,6 +1672,18 @@ template <typename V> struct ScheduleSpace {
   }
 };
 
+// deterministic build: 2^e > 1-norm of every row of the caller's matrix (both triangles)
+template <typename V>
+void compute_row_exp(int n, const int *rowptr, const V *values, std::vector<int16_t> &row_exp) {
+  row_exp.assign((size_t)n, (int16_t)-1000);
+#pragma omp parallel for schedule(static) num_threads(host_threads())
+  for (int i = 0; i < n; i++) {
+    double sum = 0.0;
+    for (int j = rowptr[i]; j < rowptr[i + 1]; j++) sum += std::fabs((double)values[j]);
+    row_exp[i] = !std::isfinite(sum) ? kExpNonFinite : (sum > 0.0 ? (int16_t)(std::ilogb(sum) + 1) : (int16_t)-1000);
+  }
+}
+
 // Build the plan for rows [row_splits[rank], row_splits[rank+1]) of the full
 // CSR.  Returns false (plan.error set) when the matrix cannot be scheduled.
 template <typename V>
@@ -1680,14 +1692,8 @@ bool build_plan(int n, const int *rowptr, const int *colind, const V *values, in
                 ScheduleSpace<V> *cache = nullptr) {
   Options opt = opt_in;
   std::vector<int16_t> row_exp;
-  if (opt.deterministic && n > 0 && rowptr && values) { // 2^e > 1-norm of every row (both triangles)
-    row_exp.assign((size_t)n, (int16_t)-1000);
-#pragma omp parallel for schedule(static) num_threads(host_threads())
-    for (int i = 0; i < n; i++) {
-      double sum = 0.0;
-      for (int j = rowptr[i]; j < rowptr[i + 1]; j++) sum += std::fabs((double)values[j]);
-      row_exp[i] = !std::isfinite(sum) ? kExpNonFinite : (sum > 0.0 ? (int16_t)(std::ilogb(sum) + 1) : (int16_t)-1000);
-    }
+  if (opt.deterministic && n > 0 && rowptr && values) {
+    compute_row_exp<V>(n, rowptr, values, row_exp);
     opt.row_exp = row_exp.data();
   }
   const int rb = row_splits_in ? row_splits_in[rank] : 0;

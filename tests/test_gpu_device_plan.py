@@ -112,6 +112,44 @@ def test_device_schedule_equals_host_schedule_on_random_matrices(seed):
     H.close()
 
 
+@pytest.mark.parametrize("name,scale,dtype", [("pwtk", 0.1, np.float64), ("Flan_1565", 0.05, np.float32),
+                                              ("tetmesh", 0.05, np.float64)])
+def test_device_schedule_of_the_deterministic_build(name, scale, dtype):
+    """CFS_HIP_FLAG_DETERMINISTIC: the smaller windows (26 bytes of LDS per slot) and the per-slot
+    scale exponents come out of the device builder as out of the host builder; bit-identical y"""
+    import torch
+    n, rp, ci, va, _ = synth.generate(name, scale)
+    va = va.astype(dtype)
+    D, H = _both(n, rp, ci, va, flags=1024)
+    _assert_same(D, H, ("deterministic", name))
+    assert D.digest()["slot_exp"] != 0
+    x = torch.from_numpy(synth.make_x(n, 42, dtype)).cuda()
+    yd, yh = torch.empty(n, dtype=x.dtype, device="cuda"), torch.empty(n, dtype=x.dtype, device="cuda")
+    D.dense_vector_multiply(yd, x)
+    H.dense_vector_multiply(yh, x)
+    torch.cuda.synchronize()
+    assert torch.equal(yd, yh)  # deterministic mode: the same bits from both handles
+    D.close()
+    H.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 4])
+def test_device_schedule_of_exchange_form_shards(nranks):
+    """CFS_HIP_FLAG_SHARD_EXCHANGE: halo columns left of the block are SENT -- the send lists
+    (rows, pointers, strip indices, counts per owner) of the device builder equal the host's"""
+    n, rp, ci, va, _ = synth.generate("Flan_1565", 0.05)
+    rs = cfs.balanced_splits(n, rp, ci, nranks)
+    for rank in range(nranks):
+        D, H = _both(n, rp, ci, va, flags=cfs.FLAG_SHARD_EXCHANGE, row_splits=rs, rank=rank)
+        _assert_same(D, H, ("exchange shard", nranks, rank))
+        assert np.array_equal(D.send_counts(), H.send_counts())
+        assert np.array_equal(D.send_rows(), H.send_rows())
+        assert D.stats()["remote_vals"] == H.stats()["remote_vals"]
+        assert (D.stats()["remote_vals"] > 0) == (rank > 0)
+        D.close()
+        H.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 3, 8])
 def test_device_schedule_of_mirrored_shards(nranks):
     import torch
