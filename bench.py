@@ -240,6 +240,23 @@ def bench_csr(args, cfs, lib, n, rp, ci, va, x_host, nnz_full, dev, t_dt, data_k
     kname = "cfs_csr_wave_kernel" if form.value == 1 else "cfs_csr_stream_kernel"
     alg = int(nnz_full * (4 + s_) + n * (4 + 2 * s_))
     achieved = alg / (kern_ms * 1e-3) / 1e9
+    streamed, narrow = C.c_int64(), C.c_int64()
+    _lib.check(lib.cfs_hip_csr_stats(A._h, C.byref(streamed), C.byref(narrow)))
+    # HBM bytes per launch from a committed PMC pass of the same kernel form over the same arrays
+    traffic, traffic_source = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            key = f"{args.matrix}:{args.scale}:{args.dtype}:csr"
+            for ent in json.load(f).get(key, []):
+                if ent.get("kernel") == kname and ent.get("bytes_streamed") == streamed.value:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_source = {"file": "profiles/hbm_traffic.json", "key": key,
+                                      "matched_on": {"kernel": kname, "bytes_streamed": streamed.value},
+                                      "measured_by": ent.get("source"),
+                                      "note": "a committed measurement of the SAME kernel form and arrays on "
+                                              "another run, not taken inside this run"}
+    except Exception:
+        traffic = None
     out = {
         "metric": f"fp{s_ * 8} general CSR SpMV GFLOP/s", "value": round(2.0 * nnz_full / (ms_per_step * 1e-3) / 1e9, 2),
         "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
@@ -255,12 +272,21 @@ def bench_csr(args, cfs, lib, n, rp, ci, va, x_host, nnz_full, dev, t_dt, data_k
                                    else " (the faster of the two forms, measured at the first SpMV)")},
         "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                      "kernel_ms": round(kern_ms, 5), "kernel_samples": len(sampled),
                      "algorithmic_bytes_per_launch": alg,
-                     "hbm_frac_of_achievable_if_traffic_equals_algorithmic":
-                         round(achieved / HBM_ACHIEVABLE_GBS, 4)},
+                     "bytes_streamed_by_format": streamed.value,
+                     "nnz_with_16bit_columns": narrow.value},
     }
+    r_ = out["roofline"]
+    if traffic:
+        wire = traffic / (kern_ms * 1e-3) / 1e9
+        r_.update({"traffic_source": traffic_source, "hbm_GBps_from_traffic": round(wire, 1),
+                   "hbm_frac_of_peak_from_traffic": round(wire / HBM_PEAK_GBS, 4),
+                   "hbm_frac_of_achievable": round(wire / HBM_ACHIEVABLE_GBS, 4),
+                   "achievable_GBps": HBM_ACHIEVABLE_GBS})
+    else:
+        r_["traffic_source"] = None
     if not args.no_cpu_baseline:
         try:
             cb = cpu_baseline(n, rp, ci, va, x_host, nnz_full, args.cpu_loops, ncpus, args.cpu_bind)

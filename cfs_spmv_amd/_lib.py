@@ -57,7 +57,7 @@ SYMBOLS = [
     "cfs_hip_sym_shard_set_recv", "cfs_hip_sym_spmv_local_async",
     "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_digest", "cfs_hip_sym_debug_plan_note", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_debug_group_features", "cfs_hip_sym_plan_check_f64",
     "cfs_hip_sym_plan_check_f32", "cfs_hip_sym_plan_send_info_f64", "cfs_hip_csr_create_f64", "cfs_hip_csr_create_f32",
-    "cfs_hip_csr_spmv", "cfs_hip_csr_spmv_async", "cfs_hip_csr_destroy", "cfs_hip_csr_kernel_form",
+    "cfs_hip_csr_spmv", "cfs_hip_csr_spmv_async", "cfs_hip_csr_destroy", "cfs_hip_csr_kernel_form", "cfs_hip_csr_stats",
     "cfs_hip_event_create", "cfs_hip_event_record", "cfs_hip_event_elapsed_ms",
     "cfs_hip_event_destroy",
 ]
@@ -140,6 +140,8 @@ def load():
     lib.cfs_hip_csr_destroy.argtypes = [vp]
     if hasattr(lib, "cfs_hip_csr_kernel_form"):
         lib.cfs_hip_csr_kernel_form.argtypes = [vp, ip, ip]
+    if hasattr(lib, "cfs_hip_csr_stats"):
+        lib.cfs_hip_csr_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.cfs_hip_event_create.argtypes = [C.POINTER(vp)]
     lib.cfs_hip_event_record.argtypes = [vp, vp]
     lib.cfs_hip_event_elapsed_ms.argtypes = [vp, vp, C.POINTER(C.c_float)]

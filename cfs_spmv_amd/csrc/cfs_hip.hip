@@ -733,6 +733,10 @@ __global__ void __launch_bounds__(256)
   send[i] = s;
 }
 
+// first position of block b's 16-bit columns (p0 = its first nonzero): a multiple of 4 (aligned
+// 8-byte loads of four codes), blocks do not overlap
+__host__ __device__ inline size_t csr_col16_offset(int p0, int b) { return ((size_t)p0 + 4 * (size_t)b + 3) & ~(size_t)3; }
+
 // general CSR, streaming form: a workgroup owns a block of consecutive rows whose
 // nonzeros fit its LDS product buffer.  All of the block's colind / values loads
 // are issued at once (16 per thread, non-temporal: the matrix is read once per
@@ -743,57 +747,93 @@ __global__ void __launch_bounds__(256)
 // a whole-workgroup strided sum.
 constexpr int kCsrNnz = 4096;  // products per workgroup (32 KiB fp64)
 constexpr int kCsrRows = 1024; // rows per block (row pointers in LDS)
-// WIDE: a lane loads PAIRS of consecutive entries (16-byte value loads, 8-byte column loads:
-// half as many load instructions for the same bytes; the gathers of a wave still walk
-// consecutive entries)
-template <typename V, bool WIDE = false>
+// LW: a lane loads LW consecutive entries at once (2: 16-byte value loads of doubles, 8-byte
+// column loads -- fewer, wider load instructions for the same bytes).  The gathers of a wave then
+// walk every LW-th entry: LW = 4 touches twice as many cache lines per gather instruction as
+// LW = 2 and is 5-19 % SLOWER on every stand-in, fp64 and fp32 (profiles/r03_experiment_notes.md)
+// -- not instantiated.
+template <typename V, int LW = 1>
 __global__ void __launch_bounds__(256)
     cfs_csr_stream_kernel(const int32_t *__restrict__ blk_row, int nblocks,
                           const int32_t *__restrict__ rowptr,
                           const int32_t *__restrict__ colind, const V *__restrict__ values,
-                          const V *__restrict__ x, V *__restrict__ y) {
+                          const V *__restrict__ x, V *__restrict__ y, int per_xcd,
+                          const uint16_t *__restrict__ col16, const int4 *__restrict__ cbase) {
   __shared__ V prod[kCsrNnz];
   __shared__ V part[256];
   __shared__ int32_t rps[kCsrRows + 1];
   const int tid = threadIdx.x;
   constexpr int PER = kCsrNnz / 256;
-  typedef V V2 __attribute__((ext_vector_type(2)));
-  typedef int I2 __attribute__((ext_vector_type(2)));
-  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+  typedef V VL __attribute__((ext_vector_type(LW > 1 ? LW : 2)));
+  typedef int IL __attribute__((ext_vector_type(LW > 1 ? LW : 2)));
+  typedef uint16_t HL __attribute__((ext_vector_type(LW > 1 ? LW : 2)));
+  // per_xcd > 0: workgroup g runs on XCD g % 8 (the grid is a multiple of 8), and XCD k walks
+  // the k-th EIGHTH of the row blocks front to back: the x window of the rows in flight is
+  // then fetched into one L2 instead of all eight
+  const int nloop = per_xcd > 0 ? per_xcd * 8 : nblocks;
+  for (int bb = blockIdx.x; bb < nloop; bb += gridDim.x) {
+    const int b = per_xcd > 0 ? (bb & 7) * per_xcd + (bb >> 3) : bb;
+    if (b >= nblocks) continue;
     const int r0 = blk_row[b], r1 = blk_row[b + 1];
     const int p0 = rowptr[r0], p1 = rowptr[r1];
     const int n = p1 - p0;
     if (n <= kCsrNnz) {
       const int nr = r1 - r0;
+      // a block whose columns fit four windows of 16 384 has them as 16-bit codes (window << 14 |
+      // offset; written once by cfs_csr_narrow_kernel): 2 bytes per nonzero instead of 4
+      const int4 cb4 = cbase ? cbase[b] : make_int4(-1, 0, 0, 0);
+      const int cb = cb4.x;
+      auto decode = [&](uint32_t h) {
+        const uint32_t k = h >> 14;
+        return (k == 0 ? cb4.x : k == 1 ? cb4.y : k == 2 ? cb4.z : cb4.w) + (int)(h & 0x3fffu);
+      };
+      const uint16_t *c16 = col16 + csr_col16_offset(p0, b);
       int rpv[kCsrRows / 256 + 1];
 #pragma unroll
       for (int u = 0; u <= kCsrRows / 256; ++u) rpv[u] = rowptr[r0 + min(tid + u * 256, nr)];
-      if (WIDE) {
-        constexpr int PW = PER / 2;
-        V2 v2[PW];
-        I2 c2[PW];
-        const int qmax = max(n - 1, 0) & ~1; // last even entry index (the arrays are padded)
+      if (LW > 1) {
+        constexpr int PW = PER / LW;
+        VL vl[PW];
+        IL cl[PW];
+        const int qmax = max(n - 1, 0) / LW * LW; // first entry of the last vector (the arrays are padded)
+        // (all loads first, the 16-bit codes are decoded only after the last one is on its way)
+        if (cb >= 0) {
+          HL hl[PW];
 #pragma unroll
-        for (int u = 0; u < PW; ++u) {
-          const int q = min(2 * (tid + u * 256), qmax);
-          v2[u] = __builtin_nontemporal_load(reinterpret_cast<const V2 *>(values + p0 + q));
-          c2[u] = __builtin_nontemporal_load(reinterpret_cast<const I2 *>(colind + p0 + q));
+          for (int u = 0; u < PW; ++u) {
+            const int q = min(LW * (tid + u * 256), qmax);
+            vl[u] = __builtin_nontemporal_load(reinterpret_cast<const VL *>(values + p0 + q));
+            hl[u] = __builtin_nontemporal_load(reinterpret_cast<const HL *>(c16 + q));
+          }
+#pragma unroll
+          for (int u = 0; u < PW; ++u)
+#pragma unroll
+            for (int j = 0; j < LW; ++j) cl[u][j] = decode(hl[u][j]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < PW; ++u) {
+            const int q = min(LW * (tid + u * 256), qmax);
+            vl[u] = __builtin_nontemporal_load(reinterpret_cast<const VL *>(values + p0 + q));
+            cl[u] = __builtin_nontemporal_load(reinterpret_cast<const IL *>(colind + p0 + q));
+          }
         }
 #pragma unroll
         for (int u = 0; u <= kCsrRows / 256; ++u)
           if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
-        V xa[PW], xb[PW];
+        V xl[PW][LW];
 #pragma unroll
         for (int u = 0; u < PW; ++u) {
-          const int q = min(2 * (tid + u * 256), qmax);
-          xa[u] = x[c2[u].x];
-          xb[u] = x[q + 1 < n ? c2[u].y : c2[u].x]; // (the entry behind an odd block's last one is not ours)
+          const int q = min(LW * (tid + u * 256), qmax);
+#pragma unroll
+          for (int j = 0; j < LW; ++j) // (an entry behind the block's last one is not ours: any valid column)
+            xl[u][j] = x[q + j < n ? cl[u][j] : cl[u][0]];
         }
 #pragma unroll
         for (int u = 0; u < PW; ++u) {
-          const int i = 2 * (tid + u * 256);
-          if (i < n) prod[i] = v2[u].x * xa[u];
-          if (i + 1 < n) prod[i + 1] = v2[u].y * xb[u];
+          const int i = LW * (tid + u * 256);
+#pragma unroll
+          for (int j = 0; j < LW; ++j)
+            if (i + j < n) prod[i + j] = vl[u][j] * xl[u][j];
         }
       } else {
         V v[PER];
@@ -802,7 +842,11 @@ __global__ void __launch_bounds__(256)
         for (int u = 0; u < PER; ++u) {
           const int q = min(tid + u * 256, max(n, 1) - 1);
           v[u] = __builtin_nontemporal_load(values + p0 + q);
-          c[u] = __builtin_nontemporal_load(colind + p0 + q);
+          c[u] = cb >= 0 ? (int)__builtin_nontemporal_load(c16 + q) : __builtin_nontemporal_load(colind + p0 + q);
+        }
+        if (cb >= 0) {
+#pragma unroll
+          for (int u = 0; u < PER; ++u) c[u] = decode((uint32_t)c[u]);
         }
 #pragma unroll
         for (int u = 0; u <= kCsrRows / 256; ++u)
@@ -837,6 +881,75 @@ __global__ void __launch_bounds__(256)
       }
       if (tid == 0) y[r0] = part[0];
       __syncthreads();
+    }
+  }
+}
+
+// once per handle: the 16-bit column codes of the block form.  The columns of a row block are
+// covered greedily by up to four windows of 16 384 columns (window k starts at the smallest
+// column not inside windows 0..k-1: banded matrices need one or two, the three planes of a 3-D
+// stencil three); a column becomes (window << 14 | offset), the four window starts go to
+// cbase[b].  A block that needs more windows (or one long row) keeps reading colind:
+// cbase[b].x = -1.
+constexpr int kCsrWinBits = 14;
+__global__ void __launch_bounds__(256)
+    cfs_csr_narrow_kernel(const int32_t *__restrict__ blk_row, int nblocks, const int32_t *__restrict__ rowptr,
+                          const int32_t *__restrict__ colind, uint16_t *__restrict__ col16,
+                          int4 *__restrict__ cbase, unsigned long long *__restrict__ narrow_nnz) {
+  __shared__ int smin[256];
+  const int tid = threadIdx.x;
+  constexpr int PER = kCsrNnz / 256, kNone = 0x7fffffff;
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    const int p0 = rowptr[blk_row[b]], p1 = rowptr[blk_row[b + 1]];
+    const int n = p1 - p0;
+    if (n > kCsrNnz || n <= 0) {
+      if (tid == 0) cbase[b] = make_int4(-1, 0, 0, 0);
+      continue;
+    }
+    int c[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) c[u] = tid + u * 256 < n ? colind[p0 + tid + u * 256] : kNone;
+    int base[4], bound = -1; // columns < bound are covered
+    bool more = true;        // (uniform) columns at or beyond `bound` exist
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int lo = kNone;
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+        if (c[u] >= bound) lo = min(lo, c[u]);
+      smin[tid] = lo;
+      __syncthreads();
+      for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) smin[tid] = min(smin[tid], smin[tid + o]);
+        __syncthreads();
+      }
+      lo = smin[0];
+      __syncthreads();
+      more = lo != kNone;
+      base[k] = more ? lo : (k ? base[k - 1] : 0);
+      if (more) bound = lo > kNone - (1 << kCsrWinBits) ? kNone : lo + (1 << kCsrWinBits);
+    }
+    // anything left beyond the fourth window?
+    int left = 0;
+#pragma unroll
+    for (int u = 0; u < PER; ++u) left |= (c[u] != kNone && c[u] >= bound) ? 1 : 0;
+    const bool narrow = __syncthreads_or(left) == 0 && base[0] >= 0;
+    if (tid == 0) {
+      cbase[b] = narrow ? make_int4(base[0], base[1], base[2], base[3]) : make_int4(-1, 0, 0, 0);
+      if (narrow) atomicAdd(narrow_nnz, (unsigned long long)n);
+    }
+    if (narrow) {
+      uint16_t *c16 = col16 + csr_col16_offset(p0, b);
+#pragma unroll
+      for (int u = 0; u < PER; ++u)
+        if (tid + u * 256 < n) {
+          // the LAST window that starts at or below the column (window starts ascend; unused ones repeat)
+          int k = 0;
+          if (c[u] >= base[1] && base[1] > base[0]) k = 1;
+          if (c[u] >= base[2] && base[2] > base[1]) k = 2;
+          if (c[u] >= base[3] && base[3] > base[2]) k = 3;
+          c16[tid + u * 256] = (uint16_t)((k << kCsrWinBits) | (c[u] - base[k]));
+        }
     }
   }
 }
@@ -1461,10 +1574,13 @@ struct cfs_hip_csr_s {
   int value_bytes = 8, nrows = 0, ncols = 0, nblocks = 0;
   int64_t nnz = 0;
   DevBuf rowptr, colind, values, blk_row;
+  DevBuf col16, cbase; // block form: 16-bit column codes of the narrow blocks, four window starts per block (x = -1: wide)
+  int64_t narrow_nnz = 0;
   DevBuf chunks, longrows; // wave-stream form: chunk descriptors, rows longer than a chunk
   int nchunks = 0, nlong = 0, wave_grid = 0, block_grid = 256 * 8;
+  bool xcd_map = true;
   bool form_measured = false; // the faster of the two kernel forms has been chosen (first SpMV)
-  bool wide = false;          // block form: pairs of entries per lane (CFS_HIP_CSR_WIDE)
+  int wide = 2;               // block form: entries per lane and load, 1 / 2 (CFS_HIP_CSR_WIDE)
   bool block_form = false; // CFS_HIP_CSR_KERNEL=block: the workgroup-per-block kernel (A/B)
   HostStage stage;
   int device = 0;
@@ -2906,6 +3022,37 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
       delete m;
       return rc;
     }
+    const char *e16 = getenv("CFS_HIP_CSR_COL16");
+    if (m->nblocks > 0 && m->nnz > 0 && !(e16 && atoi(e16) == 0)) {
+      DevBuf cnt;
+      if ((rc = m->col16.alloc(((size_t)m->nnz + 4 * (size_t)m->nblocks) * 2 + 64)) || (rc = m->cbase.alloc((size_t)m->nblocks * 16)) ||
+          (rc = cnt.alloc(8))) {
+        delete m;
+        return rc;
+      }
+      hipStream_t st = cfs_rt::home_stream();
+      unsigned long long nn = 0;
+      bool ok = hipMemsetAsync(cnt.p, 0, 8, st) == hipSuccess;
+      if (ok) {
+        hipLaunchKernelGGL(cfs_csr_narrow_kernel, dim3(std::min(m->nblocks, 4096)), dim3(256), 0, st,
+                           (const int32_t *)m->blk_row.p, m->nblocks, (const int32_t *)m->rowptr.p,
+                           (const int32_t *)m->colind.p, (uint16_t *)m->col16.p, (int4 *)m->cbase.p,
+                           (unsigned long long *)cnt.p);
+        ok = hipGetLastError() == hipSuccess &&
+             hipMemcpyAsync(&nn, cnt.p, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipStreamSynchronize(st) == hipSuccess;
+      }
+      m->narrow_nnz = (int64_t)nn;
+      // not worth the second column array when few blocks qualify
+      if (!ok || m->narrow_nnz * 2 < m->nnz) {
+        m->col16 = DevBuf();
+        m->cbase = DevBuf();
+        m->narrow_nnz = 0;
+      }
+      if (getenv("CFS_PLAN_VERBOSE"))
+        fprintf(stderr, "[cfs_hip] general CSR: %lld of %lld nonzeros in blocks with 16-bit columns\n",
+                (long long)m->narrow_nnz, (long long)m->nnz);
+    }
   }
   { // wave-stream form: chunks of whole rows (<= kCwNnz nonzeros, <= kCwRows rows); longer rows apart
     std::vector<int4> cd;
@@ -2921,6 +3068,20 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
       cd.push_back(make_int4(r, e - r, rowptr[r], rowptr[e] - rowptr[r]));
       r = e;
     }
+    m->xcd_map = true; // XCD k takes the k-th eighth of the matrix (Flan stand-in: x is then read ~once, not 8 times)
+    if (const char *e = getenv("CFS_HIP_CSR_XCD")) m->xcd_map = atoi(e) != 0;
+    if (m->xcd_map && !cd.empty()) {
+      // the same for the wave form, by the ORDER of the descriptors: workgroup g (4 waves, XCD
+      // g % 8) reads descriptors 4g .. 4g+3; empty descriptors fill the last eighth
+      const int ng = ((int)cd.size() + 3) / 4, per = (ng + 7) / 8;
+      std::vector<int4> perm((size_t)per * 32, make_int4(0, 0, 0, 0));
+      for (int g = 0; g < per * 8; g++)
+        for (int w = 0; w < 4; w++) {
+          const size_t phys = ((size_t)(g & 7) * per + (g >> 3)) * 4 + w;
+          if (phys < cd.size()) perm[(size_t)g * 4 + w] = cd[phys];
+        }
+      cd.swap(perm);
+    }
     m->nchunks = (int)cd.size();
     m->nlong = (int)lr.size();
     if ((rc = m->chunks.upload(cd.data(), cd.size() * sizeof(int4))) ||
@@ -2935,10 +3096,11 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k, 256, 0) != hipSuccess || nb < 1) nb = 4;
     if (hipGetDeviceProperties(&prop, m->device) != hipSuccess) prop.multiProcessorCount = 256;
     m->wave_grid = std::max(1, std::min((m->nchunks + 3) / 4, prop.multiProcessorCount * nb));
+    if (m->xcd_map) m->wave_grid = std::max(8, m->wave_grid & ~7);
     m->block_form = true;
     m->form_measured = false;
-    m->wide = true; // pairs of entries per lane: Flan stand-in 275-289 us against 284-294, ldoor even
-    if (const char *e = getenv("CFS_HIP_CSR_WIDE")) m->wide = atoi(e) != 0;
+    m->wide = 2; // pairs of entries per lane (Flan stand-in fp64, against single entries: 275-289 us against 284-294)
+    if (const char *e = getenv("CFS_HIP_CSR_WIDE")) m->wide = atoi(e) >= 2 ? 2 : 1;
     if (const char *e = getenv("CFS_HIP_CSR_KERNEL")) { // block | wave: no measurement
       m->block_form = strcmp(e, "wave") != 0;
       m->form_measured = true;
@@ -3012,17 +3174,20 @@ static int csr_launch(cfs_hip_csr_t h, void *y, const void *x, hipStream_t st) {
                            (const float *)h->values.p, (const float *)x, (float *)y);
     }
   } else if (h->nblocks > 0) {
-    const int grid = h->nblocks < 256 * 8 ? h->nblocks : 256 * 8;
+    const int per_xcd = h->xcd_map ? (h->nblocks + 7) / 8 : 0;
+    const int want = h->xcd_map ? per_xcd * 8 : h->nblocks;
+    const int grid = want < 256 * 8 ? want : 256 * 8;
 #define CFS_CSR_BLOCK(V, W)                                                                              \
   hipLaunchKernelGGL((cfs_csr_stream_kernel<V, W>), dim3(grid), dim3(256), 0, st, (const int32_t *)h->blk_row.p, \
                      h->nblocks, (const int32_t *)h->rowptr.p, (const int32_t *)h->colind.p,                \
-                     (const V *)h->values.p, (const V *)x, (V *)y)
+                     (const V *)h->values.p, (const V *)x, (V *)y, per_xcd, (const uint16_t *)h->col16.p,  \
+                     (const int4 *)h->cbase.p)
     if (h->value_bytes == 8) {
-      if (h->wide) CFS_CSR_BLOCK(double, true);
-      else CFS_CSR_BLOCK(double, false);
+      if (h->wide == 2) CFS_CSR_BLOCK(double, 2);
+      else CFS_CSR_BLOCK(double, 1);
     } else {
-      if (h->wide) CFS_CSR_BLOCK(float, true);
-      else CFS_CSR_BLOCK(float, false);
+      if (h->wide == 2) CFS_CSR_BLOCK(float, 2);
+      else CFS_CSR_BLOCK(float, 1);
     }
 #undef CFS_CSR_BLOCK
   }
@@ -3034,6 +3199,17 @@ int cfs_hip_csr_kernel_form(cfs_hip_csr_t h, int *form, int *measured) {
   if (!h || !form) return set_err(CFS_HIP_ERR_ARG, "null argument");
   *form = h->block_form ? CFS_HIP_CSR_FORM_BLOCK : CFS_HIP_CSR_FORM_WAVE;
   if (measured) *measured = h->form_measured ? 1 : 0;
+  return 0;
+}
+
+int cfs_hip_csr_stats(cfs_hip_csr_t h, int64_t *bytes_streamed, int64_t *narrow_nnz) {
+  if (!h) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  const int64_t vb = h->value_bytes, nz = h->nnz;
+  int64_t b = nz * vb + ((int64_t)h->nrows + 1) * 4;
+  if (h->block_form) b += h->narrow_nnz * 2 + (nz - h->narrow_nnz) * 4 + (int64_t)h->nblocks * (h->cbase.p ? 20 : 4);
+  else b += nz * 4 + (int64_t)h->nchunks * 16;
+  if (bytes_streamed) *bytes_streamed = b;
+  if (narrow_nnz) *narrow_nnz = h->block_form ? h->narrow_nnz : 0;
   return 0;
 }
 

@@ -420,6 +420,14 @@ int cfs_hip_csr_destroy(cfs_hip_csr_t h);
 #define CFS_HIP_CSR_FORM_BLOCK 0
 #define CFS_HIP_CSR_FORM_WAVE 1
 int cfs_hip_csr_kernel_form(cfs_hip_csr_t h, int *form, int *measured);
+/* The block form reads 16-bit column codes (2 bytes per nonzero instead of 4) in every row
+ * block whose columns fit into four windows of 16 384 columns (window << 14 | offset; banded
+ * matrices, 3-D stencils; written once, on the device, when the handle is created; kept when
+ * at least half of the nonzeros qualify; CFS_HIP_CSR_COL16=0: never), and
+ * both forms hand the k-th eighth of the matrix to XCD k (CFS_HIP_CSR_XCD=0: round robin).
+ * bytes_streamed = bytes one SpMV of the kept form reads from the handle's arrays;
+ * narrow_nnz = nonzeros stored with 16-bit columns.                                          */
+int cfs_hip_csr_stats(cfs_hip_csr_t h, int64_t *bytes_streamed, int64_t *narrow_nnz);
 
 /* ---- HIP-event timing on the stream the kernels run on (bench.py) --------- */
 int cfs_hip_event_create(void **ev);

@@ -184,6 +184,45 @@ def test_csr_general_parity_on_stand_ins(name, scale, form, monkeypatch):
         G.close()
 
 
+@pytest.mark.parametrize("col16", ["1", "0"])
+def test_csr_block_form_with_narrow_and_wide_row_blocks(col16, monkeypatch):
+    """the block form keeps 16-bit column codes for row blocks whose columns fit four windows of
+    16 384 and the 32-bit columns for the others: a matrix with both kinds of block (three bands
+    40 000 columns apart -- three windows --, then rows with columns anywhere in 0 .. 300 000;
+    odd row lengths so that blocks start at odd positions),
+    with and without the 16-bit array, against the long-double row sums"""
+    import scipy.sparse as sp
+    import cfs_spmv_amd as cfs
+    from oracle import oracle
+    torch = _torch()
+    monkeypatch.setenv("CFS_HIP_CSR_KERNEL", "block")
+    monkeypatch.setenv("CFS_HIP_CSR_COL16", col16)
+    rng = np.random.default_rng(5)
+    n = 300_000
+    ia = np.arange(200_000)  # stencil-like part: 5-9 entries within +-3000 columns of row - 40 000, row, row + 40 000
+    ra = np.repeat(ia, 5 + ia % 5)
+    ca = np.clip(ra + rng.choice([-40_000, 0, 40_000], ra.size) + rng.integers(-3000, 3000, ra.size), 0, n - 1)
+    ib = np.arange(200_000, 260_000)  # wide part: 3-6 entries, columns anywhere
+    rb = np.repeat(ib, 3 + ib % 4)
+    cb = rng.integers(0, n, rb.size)
+    r, c = np.concatenate([ra, rb]), np.concatenate([ca, cb])
+    A = sp.csr_matrix((rng.standard_normal(r.size), (r, c)), shape=(n, n))
+    A.sum_duplicates()
+    A.sort_indices()
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    for dtype in (np.float64, np.float32):
+        v = A.data.astype(dtype)
+        x = rng.standard_normal(n).astype(dtype)
+        G = cfs.CsrMatrix(n, n, rp, ci, v)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.full((n,), float("nan"), dtype=xd.dtype, device="cuda")
+        G.dense_vector_multiply(yd, xd)
+        torch.cuda.synchronize()
+        y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, v, x)
+        assert scaled_err(yd.cpu().numpy(), y_ld, absrow) <= TOL[dtype], (col16, dtype.__name__)
+        G.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_shards_on_one_device(nranks, dtype):

@@ -14,7 +14,14 @@ for arg in sys.argv[2:]:
     for name in ("bench.json", "kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "hbm_traffic.json"):
         shutil.copy(os.path.join(src, name), os.path.join(ROOT, "profiles", f"{rnd}_{cfg}_{name}"))
     t = json.load(open(os.path.join(src, "hbm_traffic.json")))
-    if "cfs_sym_tile_kernel" not in t:  # (a general-CSR set: no schedule to match, not in the table)
+    if "cfs_sym_tile_kernel" not in t:  # a general-CSR set: matched on the kernel form and the bytes it streams
+        kern = [k for k in t if k.startswith("cfs_csr_")][0]
+        table.setdefault(key, []).append({
+            "hbm_bytes_per_launch": t[kern]["hbm_bytes_per_launch"], "kernel": kern,
+            "bytes_streamed": t["bytes_streamed"],
+            "source": f"profiles/{rnd}_{cfg}_pmc_fetch.csv + _pmc_write.csv (rocprofv3 --pmc FETCH_SIZE / "
+                      "WRITE_SIZE, separate passes); reads = 2 x FETCH_SIZE KiB (gfx950 correction), "
+                      "writes = WRITE_SIZE KiB"})
         continue
     table.setdefault(key, []).append({
         "hbm_bytes_per_launch": t["cfs_sym_tile_kernel"]["hbm_bytes_per_launch"],
