@@ -446,6 +446,19 @@ __global__ void __launch_bounds__(BLOCK, 4)
           const double ax = fabs((double)xr[k]);
           ex = max(ex, (int)((unsigned long long)__double_as_longlong(ax) >> 52));
         }
+      // ... and of the x values its FAR entries (HYB) gather from outside the window: the
+      // scale covers them too (a second pass over their columns, L2 hits later)
+      for (int fp = wave; fp < ((t.nfar + 255) >> 8); fp += NW) {
+        const int4 cc = *reinterpret_cast<const int4 *>(d.fcols + (size_t)t.far_off + (size_t)fp * 256u + lane * 4);
+        const int e0 = fp * 256 + lane * 4;
+        const int cq[4] = {cc.x, cc.y, cc.z, cc.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (e0 + u < t.nfar) {
+            const double ax = fabs((double)x[cq[u]]);
+            ex = max(ex, (int)((unsigned long long)__double_as_longlong(ax) >> 52));
+          }
+      }
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) ex = max(ex, __shfl_xor(ex, o));
       if (lane == 0) atomicMax(&cfs_ticket[2 + det_parity], ex);
@@ -614,8 +627,7 @@ __global__ void __launch_bounds__(BLOCK, 4)
       const int4 cc = *reinterpret_cast<const int4 *>(d.fcols + base + lane * 4);
       const V x0 = x[cc.x], x1 = x[cc.y], x2 = x[cc.z], x3 = x[cc.w]; // padding: column 0
       const int e0 = fp * 256 + lane * 4;
-      // (a deterministic build has no far entries: x[col] lies outside the window
-      // whose largest |x| sets the fixed-point scale)
+      // (deterministic build: the tile's scale covers these x values too, see the window fill)
       if (e0 + 0 < t.nfar) yl.add(rr.x, (double)fv[0] * (double)x0);
       if (e0 + 1 < t.nfar) yl.add(rr.y, (double)fv[1] * (double)x1);
       if (e0 + 2 < t.nfar) yl.add(rr.z, (double)fv[2] * (double)x2);
@@ -1748,13 +1760,9 @@ static cfs_plan::Options to_opts(const cfs_hip_options *o) {
   if (const char *e = getenv("CFS_HIP_COST_MODEL")) r.cost_model = atoi(e) != 0;
   if (const char *e = getenv("CFS_HIP_COMBINE")) r.combine_siblings = atoi(e) != 0;
   if (const char *e = getenv("CFS_HIP_DETERMINISTIC")) r.deterministic = atoi(e) != 0;
-  if (r.deterministic) { // no far entries (x[col] outside the window that sets the scale); 512 / 1 024 threads
-    r.hyb = false;
-    if (r.block_threads == 256) r.block_threads = 512;
-  }
-  if ((o && (o->flags & CFS_HIP_FLAG_NO_HYB)) || r.deterministic) r.hyb = false;
-  r.count_far = !r.hyb && !r.deterministic &&
-                !(o && (o->flags & (CFS_HIP_FLAG_NO_CALIBRATE | CFS_HIP_FLAG_NO_HYB)));
+  if (r.deterministic && r.block_threads == 256) r.block_threads = 512; // 512 / 1 024 threads
+  if (o && (o->flags & CFS_HIP_FLAG_NO_HYB)) r.hyb = false;
+  r.count_far = !r.hyb && !(o && (o->flags & (CFS_HIP_FLAG_NO_CALIBRATE | CFS_HIP_FLAG_NO_HYB)));
   // tuning knob for callers that cannot pass options (the C++ surface): LDS slots
   // per tile, like CFS_NUM_THREADS for the reference's partitions
   if (r.max_slots <= 0) {

@@ -136,8 +136,9 @@ typedef struct {
  * partial sum) and accumulated with INTEGER LDS atomics -- associative, hence the same
  * bits whatever the order; the halo fold already adds in a fixed order.  The precision
  * does not depend on how the matrix is scaled.  Costs LDS (26 instead of 16 bytes per
- * slot: smaller tiles) and ALU; 512- or 1 024-thread workgroups; no far entries (their x
- * lies outside the window that sets the scale).  A NaN / Inf in x or in the matrix reads
+ * slot: smaller tiles) and ALU; 512- or 1 024-thread workgroups.  Far entries (HYB) are
+ * covered: the x values they gather from outside the window enter the tile's scale.  A
+ * contribution keeps 2^-80 of (row 1-norm) x (largest |x| the TILE reads).  A NaN / Inf in x or in the matrix reads
  * NaN in the rows it reaches.  Same tolerance against the oracle as the default.   */
 #define CFS_HIP_FLAG_DETERMINISTIC 1024
 /* keep, for every stored value of the device format, its position in the caller's CSR

@@ -125,7 +125,8 @@ def test_tune_chooses_hyb_by_measurement_and_no_hyb_forbids_it():
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("name,scale,flags", [("pwtk", 0.2, 0), ("ldoor", 0.1, 0), ("Flan_1565", 0.05, 0),
-                                              ("Flan_1565", 0.05, FLAG_NO_REORDER), ("pdb1HYS", 1.0, 0)])
+                                              ("Flan_1565", 0.05, FLAG_NO_REORDER), ("pdb1HYS", 1.0, 0),
+                                              ("ldoor", 0.1, FLAG_HYB), ("unstruct", 0.05, FLAG_HYB | FLAG_NO_REORDER)])
 def test_deterministic_mode_is_bit_reproducible(name, scale, flags, dtype):
     """CFS_HIP_FLAG_DETERMINISTIC: run the SpMV several times (the run-twice protocol of
     test/test_spmv_mmf.cpp:82-83) and on a second handle of the same matrix: identical
@@ -147,7 +148,22 @@ def test_deterministic_mode_is_bit_reproducible(name, scale, flags, dtype):
     assert np.array_equal(ys[0].view(np.uint8), _spmv(A2, x, torch).view(np.uint8))
     y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x)
     assert scaled_err(ys[0], y_ld, absrow) <= TOL[dtype]
-    assert A.stats()["far_entries"] == 0 and A.stats()["block_threads"] == 512
+    assert A.stats()["block_threads"] == 512
+    # far entries (Format::hyb) are part of the deterministic build too: their x values, gathered
+    # from outside the window, enter the tile's scale
+    assert (A.stats()["far_entries"] > 0) == bool(flags & FLAG_HYB)
+    if flags & FLAG_HYB:
+        # a few x values 2^40 above the others -- beyond the 23 bits of headroom of the fixed-point
+        # words: a tile that gathers one of them as a far entry must have it in its scale, or the
+        # sums overflow.  Same bits every run; a row whose own x values are 2^-40 of its tile's
+        # largest keeps 2^-80 of THAT scale (the mode's contract, include/cfs_hip.h): 1e-9 of its own
+        x2 = x.copy()
+        x2[:: max(1, n // 97)] *= dtype(2.0 ** 40)
+        yb = [_spmv(A, x2, torch, garbage=float(k)) for k in range(3)]
+        assert np.array_equal(yb[0].view(np.uint8), yb[1].view(np.uint8))
+        assert np.array_equal(yb[0].view(np.uint8), yb[2].view(np.uint8))
+        y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, va, x2)
+        assert scaled_err(yb[0], y_ld, absrow) <= max(TOL[dtype], 1e-9)
     A.close()
     A2.close()
 
