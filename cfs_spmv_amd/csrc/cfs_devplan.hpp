@@ -27,8 +27,11 @@
 //   cfs_value_scatter_kernel: the numbers, through the map
 // The host keeps what is sequential and small: the clustering sweep (cluster_rows), the
 // cost prefix over rows, chunk boundaries, offsets over ~500 tiles, the launch order.
-// Not covered (the host builder takes those, the same schedule either way): HYB far
-// entries, rows that are not sorted by column or hold duplicates, rows longer than 4 096.
+//   Format::hyb         dp_markfar / dp_resolve: far marks per tile (LDS hash with use counts),
+//                       the near entries compacted (scan + scatter) for everything above, the
+//                       far sections from the flags (lower ends in place, mirrored ends by a sort)
+// Not covered (the host builder takes those, the same schedule either way): rows that are
+// not sorted by column or hold duplicates, rows longer than 4 096.
 #pragma once
 
 #include <hipcub/hipcub.hpp>
@@ -170,7 +173,9 @@ __global__ void __launch_bounds__(64)
     dp_cut_kernel(const int32_t *__restrict__ chunk, int rb, int re, const int32_t *__restrict__ brp,
                   const int32_t *__restrict__ bci, const long long *__restrict__ cost, int max_slots,
                   long long max_tile_nnz, CutTile *__restrict__ out, int *__restrict__ out_count,
-                  int *__restrict__ flags) {
+                  int *__restrict__ flags, const int32_t *__restrict__ brp_all) {
+  // (brp_all: HYB -- brp / bci hold the NEAR entries only, the far ones take no slot; the
+  // length of a row that the entry cap and the 65 535 limit see still counts them)
   extern __shared__ int dp_hash[];
   const int lane = threadIdx.x, g = blockIdx.x;
   const int r0 = chunk[g], r1 = chunk[g + 1];
@@ -179,18 +184,20 @@ __global__ void __launch_bounds__(64)
   auto cut = [&](long long cap, CutTile *o) -> int {
     int nt = 0, row = r0;
     // row pointers / costs of rows [base, base + 64): lane r holds row base + r (and the end of it)
-    int base = r0 - 64, pb = 0, pe = 0;
+    int base = r0 - 64, pb = 0, pe = 0, pt = 0;
     long long pc = 0;
-    auto row_info = [&](int rw, int &b, int &len, long long &c1) {
+    auto row_info = [&](int rw, int &b, int &len, int &tot, long long &c1) {
       if (rw >= base + 64 || rw < base) {
         base = rw;
         const int q = min(rw + lane, r1 - 1) - rb;
         pb = brp[q];
         pe = brp[q + 1];
+        pt = brp_all ? brp_all[q + 1] - brp_all[q] : pe - pb;
         pc = cost[q + 1];
       }
       b = __shfl(pb, rw - base);
       len = __shfl(pe, rw - base) - b;
+      tot = __shfl(pt, rw - base);
       c1 = __shfl(pc, rw - base);
     };
     while (row < r1) {
@@ -200,9 +207,9 @@ __global__ void __launch_bounds__(64)
       long long nnz = 0;
       const long long c0 = cost[row - rb];
       while (row < r1) {
-        int b, len;
+        int b, len, tot;
         long long c1;
-        row_info(row, b, len, c1);
+        row_info(row, b, len, tot, c1);
         int mynew = 0;
         for (int q = b + lane; q < b + len; q += 64) {
           const int c = bci[q];
@@ -211,9 +218,9 @@ __global__ void __launch_bounds__(64)
 #pragma unroll
         for (int o2 = 32; o2 > 0; o2 >>= 1) mynew += __shfl_xor(mynew, o2);
         const int newh = mynew;
-        const bool fits = (nown + 1 + nhalo + newh <= max_slots) && (nnz + len <= max_tile_nnz || nown == 0) &&
+        const bool fits = (nown + 1 + nhalo + newh <= max_slots) && (nnz + tot <= max_tile_nnz || nown == 0) &&
                           nown < 65535 && (c1 - c0 <= cap || nown == 0);
-        if (len > 65535 && lane == 0) atomicAdd(&flags[F_DENSEROW], 1);
+        if (tot > 65535 && lane == 0) atomicAdd(&flags[F_DENSEROW], 1);
         if (!fits) {
           if (nown == 0) {
             if (lane == 0) atomicAdd(&flags[F_DENSEROW], 1);
@@ -223,7 +230,7 @@ __global__ void __launch_bounds__(64)
         }
         nown++;
         nhalo += newh;
-        nnz += len;
+        nnz += tot;
         row++;
       }
       if (lane == 0) o[nt] = CutTile{row0, nown, nown + nhalo}; // (at most one tile per row: o has r1 - r0 places)
@@ -240,6 +247,154 @@ __global__ void __launch_bounds__(64)
     const int nb = cut(cc / na + cc / 64 + 1, ob);
     if (lane == 0) out_count[2 * g + 1] = nb;
   }
+}
+
+// position of value j of lane l in a packet of cnt lanes (cfs_plan::packet_val_pos)
+template <int VS> // sizeof(V)
+__device__ __forceinline__ int pkt_val_pos(int l, int j, int cnt) {
+  return VS == 8 ? (j >> 1) * 2 * cnt + l * 2 + (j & 1) : l * 4 + j;
+}
+
+// ---- HYB (Format::hyb): which entries leave the tile format? ------------------------------------
+// cfs_plan::Builder::mark_far for the tiles of a first cut: an entry whose column is an in-block
+// halo column of its tile (left of the tile's first row) that the tile uses at most `thr` times.
+// One workgroup per tile; LDS: hash set of the halo columns [kHashSize] + a use count each.
+__device__ __forceinline__ int hash_slot(int *hash, int c) { // index of c in the set (inserted if new)
+  const int key = c + 1;
+  unsigned h = hash_col(c);
+  for (int probe = 0; probe < kHashSize; ++probe) {
+    const int old = atomicCAS(&hash[h], 0, key);
+    if (old == 0 || old == key) return (int)h;
+    h = (h + 1) & (kHashSize - 1);
+  }
+  return 0;
+}
+__global__ void __launch_bounds__(kBlock)
+    dp_markfar_kernel(const Tile *__restrict__ tiles, int rb, int thr, const int32_t *__restrict__ brp,
+                      const int32_t *__restrict__ bci, uint8_t *__restrict__ far,
+                      unsigned long long *__restrict__ ctr) {
+  extern __shared__ int dp_lds[];
+  int *hash = dp_lds, *uses = dp_lds + kHashSize;
+  const Tile t = tiles[blockIdx.x];
+  const int tid = threadIdx.x, row0 = t.row0, lr0 = row0 - rb;
+  for (int h = tid; h < kHashSize; h += kBlock) hash[h] = uses[h] = 0;
+  __syncthreads();
+  const int eb = brp[lr0], ee = brp[lr0 + t.nown];
+  for (int q = eb + tid; q < ee; q += kBlock) {
+    const int c = bci[q];
+    if (c < row0 && c >= rb) atomicAdd(&uses[hash_slot(hash, c)], 1);
+  }
+  __syncthreads();
+  unsigned long long mine = 0;
+  for (int q = eb + tid; q < ee; q += kBlock) {
+    const int c = bci[q];
+    if (c < row0 && c >= rb && uses[hash_slot(hash, c)] <= thr) {
+      far[q] = 1;
+      mine++;
+    }
+  }
+  if (mine) atomicAdd(&ctr[C_FARCAND], mine);
+}
+__global__ void __launch_bounds__(kBlock)
+    dp_tileofrow_kernel(const Tile *__restrict__ tiles, int rb, int32_t *__restrict__ tor) {
+  const Tile t = tiles[blockIdx.x];
+  for (int r = threadIdx.x; r < t.nown; r += kBlock) tor[t.row0 - rb + r] = blockIdx.x;
+}
+// cfs_plan::Builder::resolve_far: a marked entry whose two rows ended up in one tile is an ordinary
+// entry again; farL / farU = far entries of a row as the lower / the mirrored (upper) end
+__global__ void __launch_bounds__(kBlock)
+    dp_resolve_kernel(int rows, int rb, const int32_t *__restrict__ brp, const int32_t *__restrict__ bci,
+                      const int32_t *__restrict__ tor, uint8_t *__restrict__ far, int32_t *__restrict__ farL,
+                      int32_t *__restrict__ farU, unsigned long long *__restrict__ kept) {
+  const int r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  const int mine = tor[r];
+  int low = 0;
+  for (int q = brp[r]; q < brp[r + 1]; ++q) {
+    if (!far[q]) continue;
+    const int c = bci[q] - rb;
+    if (tor[c] == mine) {
+      far[q] = 0;
+      continue;
+    }
+    low++;
+    atomicAdd(&farU[c], 1);
+  }
+  farL[r] = low;
+  if (low) atomicAdd(kept, (unsigned long long)low);
+}
+// the NEAR entries of the schedule-space matrix, compacted: everything downstream of the cut
+// (virtual rows, leaders, packets, slot tables, fold index) reads these arrays
+__global__ void __launch_bounds__(kBlock)
+    dp_nearflag_kernel(const uint8_t *__restrict__ far, long long nst, int32_t *__restrict__ nf) {
+  const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (q <= nst) nf[q] = q < nst && !far[q] ? 1 : 0;
+}
+__global__ void __launch_bounds__(kBlock)
+    dp_compact_kernel(const uint8_t *__restrict__ far, const int32_t *__restrict__ pos, long long nst,
+                      const int32_t *__restrict__ bci, const int32_t *__restrict__ bsrc,
+                      int32_t *__restrict__ bci_n, int32_t *__restrict__ bsrc_n) {
+  const long long q = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (q >= nst || far[q]) return;
+  bci_n[pos[q]] = bci[q];
+  bsrc_n[pos[q]] = bsrc[q];
+}
+__global__ void __launch_bounds__(kBlock)
+    dp_nearrows_kernel(int rows, const int32_t *__restrict__ brp, const int32_t *__restrict__ pos,
+                       int32_t *__restrict__ brp_n) {
+  const int r = blockIdx.x * kBlock + threadIdx.x;
+  if (r <= rows) brp_n[r] = pos[brp[r]];
+}
+// far sections (cfs_plan::Builder::fill_streams): per tile the far entries of its own rows in row /
+// entry order [0, nfar_low), then the mirror images of other tiles' far entries that end in its
+// rows, sorted by (row, original column) [nfar_low, nfar); 256-entry packets, packet value layout.
+// PL / PU = exclusive prefixes of farL / farU over the rows.
+template <int VS>
+__global__ void __launch_bounds__(kBlock)
+    dp_farlow_kernel(int rows, int rb, const Tile *__restrict__ tiles, const int32_t *__restrict__ tor,
+                     const int32_t *__restrict__ brp, const int32_t *__restrict__ bci,
+                     const int32_t *__restrict__ bsrc, const uint8_t *__restrict__ far,
+                     const int32_t *__restrict__ PL, const int32_t *__restrict__ perm,
+                     uint16_t *__restrict__ frows, int32_t *__restrict__ fcols, int32_t *__restrict__ fval_map,
+                     uint64_t *__restrict__ upkey, int32_t *__restrict__ uppay) {
+  const int r = blockIdx.x * kBlock + threadIdx.x;
+  if (r >= rows) return;
+  const Tile t = tiles[tor[r]];
+  const int lr0 = t.row0 - rb;
+  int e = PL[r] - PL[lr0], g = PL[r];
+  const unsigned orig_r = (unsigned)(perm ? perm[r] : rb + r);
+  for (int q = brp[r]; q < brp[r + 1]; ++q) {
+    if (!far[q]) continue;
+    const int c = bci[q];
+    const int pk = e >> 8, l = (e & 255) >> 2, j = e & 3;
+    const long long at = (long long)t.far_off + (long long)pk * 256;
+    frows[at + l * 4 + j] = (uint16_t)(r - lr0);
+    fcols[at + l * 4 + j] = perm ? perm[c - rb] : c;
+    fval_map[at + pkt_val_pos<VS>(l, j, 64)] = bsrc[q];
+    upkey[g] = ((uint64_t)(unsigned)(c - rb) << 32) | orig_r;
+    uppay[g] = bsrc[q];
+    ++e;
+    ++g;
+  }
+}
+template <int VS>
+__global__ void __launch_bounds__(kBlock)
+    dp_farup_kernel(long long K, int rb, const Tile *__restrict__ tiles, const int32_t *__restrict__ tor,
+                    const uint64_t *__restrict__ skey, const int32_t *__restrict__ spay,
+                    const int32_t *__restrict__ PU, uint16_t *__restrict__ frows, int32_t *__restrict__ fcols,
+                    int32_t *__restrict__ fval_map) {
+  const long long u = (long long)blockIdx.x * kBlock + threadIdx.x;
+  if (u >= K) return;
+  const uint64_t k = skey[u];
+  const int cl = (int)(k >> 32);
+  const Tile t = tiles[tor[cl]];
+  const int lr0 = t.row0 - rb;
+  const int e = t.nfar_low + (int)(u - PU[lr0]);
+  const int pk = e >> 8, l = (e & 255) >> 2, j = e & 3;
+  const long long at = (long long)t.far_off + (long long)pk * 256;
+  frows[at + l * 4 + j] = (uint16_t)(cl - lr0);
+  fcols[at + l * 4 + j] = (int32_t)(unsigned)(k & 0xffffffffu);
+  fval_map[at + pkt_val_pos<VS>(l, j, 64)] = spay[u];
 }
 
 // ---- per tile: packet cap of a virtual row, virtual rows, COO leftovers ---------------------
@@ -554,10 +709,6 @@ __global__ void __launch_bounds__(kBlock)
 // Values are not touched here: every stored value of the device format gets the POSITION of
 // its number in the uploaded value array (val_map / cval_map / diag_map); the numbers follow
 // through cfs_value_scatter_kernel -- the same kernel that refreshes them later.
-template <int VS> // sizeof(V)
-__device__ __forceinline__ int pkt_val_pos(int l, int j, int cnt) {
-  return VS == 8 ? (j >> 1) * 2 * cnt + l * 2 + (j & 1) : l * 4 + j;
-}
 template <int VS>
 __global__ void __launch_bounds__(kBlock)
     dp_fill_kernel(Tile *__restrict__ tiles, int rb, int re, int mirror, int far_thr,
@@ -848,7 +999,14 @@ template <typename V> struct Input {
 // window shapes, the clusters of the coarser schedule are pairs of the finer one's -- same row
 // order, same schedule-space matrix, no second upload
 template <typename V> struct Kept {
-  Input<V> in;
+  Input<V> in; // the upload: every later build of these rows reads it (tune() makes up to three)
+  bool mirror = false;
+  // the last clustered placement and the clusters it belongs to (a build with the same clusters, or
+  // with pairs of them, reuses it: no sweep of the host, no sort)
+  bool has_sc = false;
+  int nc = 0, max_slots = 0;
+  bool cost_model = false;
+  std::vector<int32_t> perm, chunk;
   Sched SC;
 };
 
@@ -987,19 +1145,16 @@ int place(const Input<V> &in, int rb, int re, bool mirror, const std::vector<int
   HIPCHK(hipMemcpy(&last, (const int32_t *)S.brp.p + rows, 4, hipMemcpyDeviceToHost));
   S.nst = last;
   S.keys2 = DevBuf();
-  // cost prefix of the rows (cfs_plan::Builder::count_rows, no far entries)
-  S.cost.assign((size_t)rows + 1, 0);
-  for (int r = 0; r < rows; r++)
-    S.cost[r + 1] = S.cost[r] + (int64_t)S.h_lcnt[r] * (int64_t)(sizeof(V) + 2) + (int64_t)(4 + 3 * sizeof(V)) +
-                    2 * (int64_t)sizeof(V);
-  pt.lap("  place: frees, cost prefix");
+  // cost prefix of the rows (cfs_plan::Builder::count_rows, no far entries): in build()
+  pt.lap("  place: frees");
   return 0;
 }
 
 // chunks -> tiles on the device; fills S.tiles / S.group_ptr / S.nhalo
 template <typename V>
 int cut_tiles(Sched &S, const cfs_plan::ChunkLayout &L, const cfs_plan::Options &opt, DevBuf &flags,
-              std::string &why) {
+              std::string &why, const Sched *near = nullptr) {
+  // (near: HYB -- the matrix without its far entries, which take no slot)
   const int nc = L.nchunks(), rows = S.rows, rb = S.rb;
   int rc;
   DevBuf d_chunk, d_cost, d_out, d_cnt;
@@ -1011,8 +1166,9 @@ int cut_tiles(Sched &S, const cfs_plan::ChunkLayout &L, const cfs_plan::Options 
   HIPCHK(hipFuncSetAttribute((const void *)dp_cut_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                              kHashSize * 4));
   hipLaunchKernelGGL(dp_cut_kernel, dim3(nc), dim3(64), kHashSize * 4, 0, (const int32_t *)d_chunk.p, rb, S.re,
-                     (const int32_t *)S.brp.p, (const int32_t *)S.bci.p, (const long long *)d_cost.p, L.max_slots,
-                     max_tile_nnz, (CutTile *)d_out.p, (int *)d_cnt.p, (int *)flags.p);
+                     (const int32_t *)(near ? near->brp.p : S.brp.p), (const int32_t *)(near ? near->bci.p : S.bci.p),
+                     (const long long *)d_cost.p, L.max_slots, max_tile_nnz, (CutTile *)d_out.p, (int *)d_cnt.p,
+                     (int *)flags.p, near ? (const int32_t *)S.brp.p : (const int32_t *)nullptr);
   HIPCHK(hipGetLastError());
   std::vector<CutTile> out((size_t)2 * std::max(rows, 1));
   std::vector<int> cnt((size_t)nc * 2);
@@ -1043,6 +1199,148 @@ int cut_tiles(Sched &S, const cfs_plan::ChunkLayout &L, const cfs_plan::Options 
   return 0;
 }
 
+template <typename T> inline int dl(std::vector<T> &dst, const DevBuf &src, size_t count) {
+  dst.resize(count);
+  if (count) HIPCHK(hipMemcpy(dst.data(), src.p, count * sizeof(T), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// cost prefix of the rows (cfs_plan::Builder::count_rows); farL / farU: far entries of a row as the
+// lower / the mirrored end (NULL: none)
+template <typename V> void row_costs(Sched &S, const int32_t *farL, const int32_t *farU) {
+  const int rows = S.rows;
+  S.cost.assign((size_t)rows + 1, 0);
+  for (int r = 0; r < rows; r++) {
+    const int64_t fl = farL ? farL[r] : 0, fu = farU ? farU[r] : 0;
+    S.cost[r + 1] = S.cost[r] + ((int64_t)S.h_lcnt[r] - fl) * (int64_t)(sizeof(V) + 2) +
+                    (farL ? (fl + fu) * (int64_t)(2 * sizeof(V) + 6) : 0) + (int64_t)(4 + 3 * sizeof(V)) +
+                    2 * (int64_t)sizeof(V);
+  }
+}
+
+// HYB state of one row order: which stored entries are far, and the matrix without them
+struct FarState {
+  bool active = false;         // far entries exist; `near` holds everything else
+  long long marked = 0, kept = 0;
+  DevBuf far, farL, farU, tor; // flag per stored entry; per row: far entries as lower / upper end; tile of a row
+  std::vector<int32_t> h_farL, h_farU;
+  Sched near; // brp / bci / kv2 (value positions) / lcnt / firstcol of the near entries
+};
+
+// near <- the entries of S that are not flagged
+inline int compact_near(const Sched &S, FarState &F, Scratch &tmp, DevBuf &flags) {
+  const long long nst = S.nst;
+  const int rows = S.rows;
+  int rc;
+  DevBuf nf, pos;
+  if ((rc = nf.alloc(((size_t)nst + 1) * 4)) || (rc = pos.alloc(((size_t)nst + 1) * 4))) return rc;
+  hipLaunchKernelGGL(dp_nearflag_kernel, dim3((unsigned)((nst + 1 + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0,
+                     (const uint8_t *)F.far.p, nst, (int32_t *)nf.p);
+  size_t tb = 0;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, (const int32_t *)nf.p, (int32_t *)pos.p, (int)(nst + 1),
+                                          (hipStream_t)0));
+  if ((rc = tmp.need(tb))) return rc;
+  tb = tmp.buf.bytes;
+  HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.buf.p, tb, (const int32_t *)nf.p, (int32_t *)pos.p, (int)(nst + 1),
+                                          (hipStream_t)0));
+  int32_t nn = 0;
+  HIPCHK(hipMemcpy(&nn, (const int32_t *)pos.p + nst, 4, hipMemcpyDeviceToHost));
+  Sched &N = F.near;
+  N.rb = S.rb;
+  N.re = S.re;
+  N.rows = rows;
+  N.nl = S.nl;
+  N.nst = nn;
+  if ((rc = N.brp.alloc(((size_t)rows + 2) * 4)) || (rc = N.bci.alloc(((size_t)nn + 1) * 4)) ||
+      (rc = N.kv2.alloc(((size_t)nn + 1) * 4)) || (rc = N.lcnt.alloc((size_t)rows * 4 + 4)) ||
+      (rc = N.firstcol.alloc((size_t)rows * 4 + 4)))
+    return rc;
+  if (nst > 0)
+    hipLaunchKernelGGL(dp_compact_kernel, dim3((unsigned)((nst + kBlock - 1) / kBlock)), dim3(kBlock), 0, 0,
+                       (const uint8_t *)F.far.p, (const int32_t *)pos.p, nst, (const int32_t *)S.bci.p, S.bsrc(),
+                       (int32_t *)N.bci.p, (int32_t *)N.kv2.p);
+  hipLaunchKernelGGL(dp_nearrows_kernel, dim3((rows + 1 + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, rows,
+                     (const int32_t *)S.brp.p, (const int32_t *)pos.p, (int32_t *)N.brp.p);
+  if (rows > 0)
+    hipLaunchKernelGGL(dp_lcnt_kernel, dim3((rows + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, rows,
+                       (const int32_t *)N.brp.p, (const int32_t *)N.bci.p, (int32_t *)N.lcnt.p,
+                       (int32_t *)N.firstcol.p, (int *)flags.p);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipDeviceSynchronize()); // nf / pos go out of scope
+  return 0;
+}
+
+// tile of every row; far marks of pairs inside one tile cleared; farL / farU / kept
+inline int resolve_far(const Sched &S, FarState &F) {
+  const int rows = S.rows, T = (int)S.tiles.size();
+  int rc;
+  DevBuf d_t, d_kept;
+  if ((rc = d_t.upload(S.tiles.data(), (size_t)T * sizeof(Tile))) || (rc = d_kept.alloc(8))) return rc;
+  if (!F.tor.p && (rc = F.tor.alloc((size_t)rows * 4 + 4))) return rc;
+  if (!F.farL.p && ((rc = F.farL.alloc(((size_t)rows + 1) * 4)) || (rc = F.farU.alloc(((size_t)rows + 1) * 4)))) return rc;
+  HIPCHK(hipMemsetAsync(F.farL.p, 0, ((size_t)rows + 1) * 4, 0));
+  HIPCHK(hipMemsetAsync(F.farU.p, 0, ((size_t)rows + 1) * 4, 0));
+  HIPCHK(hipMemsetAsync(d_kept.p, 0, 8, 0));
+  hipLaunchKernelGGL(dp_tileofrow_kernel, dim3(T), dim3(kBlock), 0, 0, (const Tile *)d_t.p, S.rb, (int32_t *)F.tor.p);
+  hipLaunchKernelGGL(dp_resolve_kernel, dim3((rows + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, rows, S.rb,
+                     (const int32_t *)S.brp.p, (const int32_t *)S.bci.p, (const int32_t *)F.tor.p, (uint8_t *)F.far.p,
+                     (int32_t *)F.farL.p, (int32_t *)F.farU.p, (unsigned long long *)d_kept.p);
+  HIPCHK(hipGetLastError());
+  unsigned long long k = 0;
+  HIPCHK(hipMemcpy(&k, d_kept.p, 8, hipMemcpyDeviceToHost));
+  F.kept = (long long)k;
+  if ((rc = dl(F.h_farL, F.farL, (size_t)rows)) || (rc = dl(F.h_farU, F.farU, (size_t)rows))) return rc;
+  return 0;
+}
+
+// the cut of one row order with Format::hyb -- the sequence of cfs_plan::Builder::run: first cut,
+// far marks, cut again without them, resolve; with far entries left: costs (and, in natural
+// order, chunk boundaries) once more, final cut, resolve, costs.  S.chunk and the base costs are set.
+template <typename V, class NaturalChunks>
+int hyb_cut(Sched &S, FarState &F, const cfs_plan::ChunkLayout &L, const cfs_plan::Options &opt, bool natural,
+            NaturalChunks &&natural_chunks, Scratch &tmp, DevBuf &flags, DevBuf &ctr, std::string &why) {
+  int rc;
+  F.active = false;
+  F.marked = F.kept = 0;
+  if ((rc = cut_tiles<V>(S, L, opt, flags, why))) return rc;
+  if (S.rows == 0 || S.nst == 0) return 0;
+  const int T1 = (int)S.tiles.size();
+  if ((rc = F.far.alloc((size_t)S.nst + 1))) return rc;
+  HIPCHK(hipMemsetAsync(F.far.p, 0, (size_t)S.nst + 1, 0));
+  HIPCHK(hipMemsetAsync((char *)ctr.p + C_FARCAND * 8, 0, 8, 0));
+  {
+    DevBuf d_t;
+    if ((rc = d_t.upload(S.tiles.data(), (size_t)T1 * sizeof(Tile)))) return rc;
+    HIPCHK(hipFuncSetAttribute((const void *)dp_markfar_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               2 * kHashSize * 4));
+    hipLaunchKernelGGL(dp_markfar_kernel, dim3(T1), dim3(kBlock), 2 * kHashSize * 4, 0, (const Tile *)d_t.p, S.rb,
+                       std::max(1, opt.far_uses), (const int32_t *)S.brp.p, (const int32_t *)S.bci.p,
+                       (uint8_t *)F.far.p, (unsigned long long *)ctr.p);
+    HIPCHK(hipGetLastError());
+    unsigned long long mk = 0;
+    HIPCHK(hipMemcpy(&mk, (const char *)ctr.p + C_FARCAND * 8, 8, hipMemcpyDeviceToHost));
+    F.marked = (long long)mk;
+  }
+  if (F.marked == 0) return 0; // (the host cuts once more: the same tiles)
+  if ((rc = compact_near(S, F, tmp, flags))) return rc;
+  if ((rc = cut_tiles<V>(S, L, opt, flags, why, &F.near))) return rc;
+  if ((rc = resolve_far(S, F))) return rc;
+  if (F.kept == 0) return 0;
+  row_costs<V>(S, F.h_farL.data(), F.h_farU.data());
+  if (natural) natural_chunks(S);
+  if ((rc = compact_near(S, F, tmp, flags))) return rc;
+  if ((rc = cut_tiles<V>(S, L, opt, flags, why, &F.near))) return rc;
+  if ((rc = resolve_far(S, F))) return rc;
+  if (F.kept == 0) {
+    row_costs<V>(S, nullptr, nullptr);
+    return 0;
+  }
+  row_costs<V>(S, F.h_farL.data(), F.h_farU.data());
+  if ((rc = compact_near(S, F, tmp, flags))) return rc;
+  F.active = true;
+  return 0;
+}
+
 __global__ void dp_bounds_kernel(const uint32_t *__restrict__ skeys, int H, unsigned rb, unsigned re,
                                  int32_t *__restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1059,11 +1357,6 @@ __global__ void dp_bounds_kernel(const uint32_t *__restrict__ skeys, int H, unsi
   out[1] = lb(re);
 }
 
-template <typename T> inline int dl(std::vector<T> &dst, const DevBuf &src, size_t count) {
-  dst.resize(count);
-  if (count) HIPCHK(hipMemcpy(dst.data(), src.p, count * sizeof(T), hipMemcpyDeviceToHost));
-  return 0;
-}
 
 // what the caller (sym_create) may reuse for a second build with half as many groups:
 // the clustered row order (cfs_plan::ScheduleSpace holds perm / chunk; device_only marks that
@@ -1083,7 +1376,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   if (rb < 0 || re > n || rb > re) return kUseHost; // the host builder reports it
   const int rows = re - rb;
   const bool mirror = opt.mirror_offblock && nranks > 1;
-  if (opt.hyb || !opt.group_share.empty() || rows < 1 ||
+  if (!opt.group_share.empty() || rows < 1 ||
       (opt.block_threads != 0 && opt.block_threads != 256 && opt.block_threads != 512 && opt.block_threads != 1024)) {
     why = "option not covered by the device builder";
     return kUseHost;
@@ -1114,21 +1407,30 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   unsigned long long h_ctr[C_COUNT] = {0};
   Scratch tmp;
   const bool may_cluster = opt.reorder && opt.force_order != 1 && rows >= 256;
-  // a kept placement of these rows (tune()'s second window shape): nothing to upload or place
-  Kept<V> *K = nullptr;
-  if (may_cluster && cache && cache->valid && cache->device_keep && cache->rb == rb && cache->re == re &&
-      cache->nchunks == 2 * nc)
-    K = static_cast<Kept<V> *>(cache->device_keep.get());
+  // what an earlier build of these rows left on the device (tune() builds up to three schedules:
+  // two window shapes, Format::hyb): the upload always; the clustered placement when this build
+  // has the same clusters (same count, window and cost model) or pairs of them (the second shape
+  // after a clustered first one -- the rule of cfs_plan::build_plan)
+  Kept<V> *KP = nullptr;
+  if (cache && cache->device_keep && cache->rb == rb && cache->re == re) {
+    KP = static_cast<Kept<V> *>(cache->device_keep.get());
+    if (KP->mirror != mirror || !KP->in.rowptr.p || !KP->in.colind.p) KP = nullptr;
+  }
+  const bool same_clusters = KP && may_cluster && KP->has_sc && KP->nc == nc && KP->max_slots == L.max_slots &&
+                             KP->cost_model == opt.cost_model;
+  const bool pair_clusters = KP && may_cluster && KP->has_sc && cache->valid && cache->nchunks == 2 * nc &&
+                             KP->nc == 2 * nc && !same_clusters;
+  Kept<V> *K = (same_clusters || pair_clusters) ? KP : nullptr; // (the placement too)
   Input<V> in_local;
   Sched SC_local, SN, *S = nullptr;
-  Input<V> &in = K ? K->in : in_local;
+  Input<V> &in = KP ? KP->in : in_local;
   Sched &SC = K ? K->SC : SC_local;
   // the upload of the caller's CSR (PCIe, all host threads copy into the page-locked pieces)
   // runs beside the clustering sweep of the host, which only reads the caller's arrays
   int up_rc = 0, cur_dev = 0;
   std::string up_err;
   HIPCHK(hipGetDevice(&cur_dev));
-  if (!K) scan_input<V>(n, rowptr, colind, rb, re, mirror, in); // row prefixes col <= row (binary searches)
+  if (!KP) scan_input<V>(n, rowptr, colind, rb, re, mirror, in); // row prefixes col <= row (binary searches)
   auto do_upload = [&]() {
     (void)hipSetDevice(cur_dev);
     up_rc = upload_input<V>(n, rowptr, colind, values, in);
@@ -1136,7 +1438,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   };
   std::thread uploader;
   bool threaded = false;
-  if (!K) {
+  if (!KP) {
     try {
       uploader = std::thread(do_upload);
       threaded = true;
@@ -1168,7 +1470,12 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   std::vector<int32_t> perm, cchunk;
   bool have_clusters = false;
   if (may_cluster) {
-    if (cache && cache->valid && cache->rb == rb && cache->re == re && cache->nchunks == 2 * nc) {
+    if (same_clusters) { // the sweep would find the same clusters again
+      perm = KP->perm;
+      cchunk = KP->chunk;
+      have_clusters = true;
+    } else if (cache && cache->valid && cache->rb == rb && cache->re == re && cache->nchunks == 2 * nc &&
+               (pair_clusters || !cache->device_only)) {
       perm = cache->perm; // the coarser schedule's clusters are pairs of the finer one's
       cchunk.resize((size_t)nc + 1);
       for (int g = 0; g <= nc; g++) cchunk[g] = cache->chunk[2 * g];
@@ -1177,7 +1484,9 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
       cluster_rows<V>(n, rowptr, colind, rb, re, nc, L.shares(opt), perm, cchunk, mirror, L.cluster_cost(opt));
       have_clusters = true;
       if (cache) {
+        std::shared_ptr<void> keepalive = cache->device_keep; // (the upload outlives the clusters)
         cache->drop();
+        cache->device_keep = keepalive;
         cache->perm = perm;
         cache->chunk = cchunk;
         cache->rb = rb;
@@ -1194,7 +1503,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   if (res_rc) return res_rc;
   pt.lap("device: upload CSR || cluster_rows (host)");
   bool use_clustered = have_clusters;
-  const bool reused = have_clusters && cache && cache->valid && cache->nchunks == 2 * nc;
+  const bool reused = have_clusters && !same_clusters && cache && cache->valid && cache->nchunks == 2 * nc;
   auto natural_chunks = [&](Sched &X) { // cfs_plan::Builder::cut_chunks
     X.chunk.assign((size_t)nc + 1, re);
     X.chunk[0] = rb;
@@ -1210,6 +1519,13 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     }
     X.chunk[nc] = re;
   };
+  FarState FC, FN; // Format::hyb: the far entries of either order
+  auto cut = [&](Sched &X, FarState &F, bool natural) -> int {
+    row_costs<V>(X, nullptr, nullptr); // (a kept placement may hold the costs of an earlier HYB build)
+    if (natural) natural_chunks(X);
+    if (!opt.hyb) return cut_tiles<V>(X, L, opt, flags, why);
+    return hyb_cut<V>(X, F, L, opt, natural, natural_chunks, tmp, flags, ctr, why);
+  };
   if (have_clusters) {
     if (!K) {
       rc = place<V>(in, rb, re, mirror, &perm, SC, tmp, flags, h_ctr, ctr, why);
@@ -1218,15 +1534,14 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
       HIPCHK(hipMemsetAsync(ctr.p, 0, C_COUNT * 8, 0)); // (place() would have)
     }
     SC.chunk = cchunk;
-    if ((rc = cut_tiles<V>(SC, L, opt, flags, why)) < 0) return rc;
+    if ((rc = cut(SC, FC, false)) < 0) return rc;
     const bool c_ok = rc == 0;
     if (!c_ok) HIPCHK(hipMemset(flags.p, 0, F_COUNT * sizeof(int))); // natural order may still do
     pt.lap("device: clustered order placed + cut");
     if (opt.force_order != 2 && !reused) {
       rc = place<V>(in, rb, re, mirror, nullptr, SN, tmp, flags, h_ctr, ctr, why);
       if (rc) return rc;
-      natural_chunks(SN);
-      if ((rc = cut_tiles<V>(SN, L, opt, flags, why)) < 0) return rc;
+      if ((rc = cut(SN, FN, true)) < 0) return rc;
       const bool n_ok = rc == 0;
       if (!n_ok && !c_ok) return kUseHost;
       if (!n_ok) HIPCHK(hipMemset(flags.p, 0, F_COUNT * sizeof(int)));
@@ -1245,24 +1560,28 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     }
     if (cache && cache->device_only) cache->valid = cache->valid && use_clustered; // reusable only if kept
   }
+  const std::vector<int32_t> perm_all = (cache && have_clusters && !K) ? perm : std::vector<int32_t>(); // for Kept
   if (use_clustered) {
     S = &SC;
     SN = Sched();
-  } else if (K) {
-    return kUseHost; // (cannot happen: a kept placement is only offered for the clustered order)
+  } else if (K && !same_clusters) {
+    return kUseHost; // (cannot happen: pairs of kept clusters are only offered for the clustered order)
   } else {
     if (!SN.rows && rows) {
       rc = place<V>(in, rb, re, mirror, nullptr, SN, tmp, flags, h_ctr, ctr, why);
       if (rc) return rc;
-      natural_chunks(SN);
-      if ((rc = cut_tiles<V>(SN, L, opt, flags, why))) return rc;
+      if ((rc = cut(SN, FN, true))) return rc;
       pt.lap("device: natural order placed + cut");
     }
     S = &SN;
-    SC_local = Sched();
+    if (!cache) SC_local = Sched(); // (a cache keeps the clustered placement for a later build)
     perm.clear();
   }
-  in.colind = DevBuf(); // the structure of the caller's matrix has been read
+  if (!cache) in.colind = DevBuf(); // the structure of the caller's matrix has been read (a cache keeps the upload)
+  // Format::hyb: everything below reads the matrix WITHOUT its far entries
+  FarState &FS = use_clustered ? FC : FN;
+  (use_clustered ? FN : FC) = FarState();
+  const Sched *M = FS.active ? &FS.near : S;
 
   // ---- per tile: virtual rows -------------------------------------------------------------------
   std::vector<Tile> &tiles = S->tiles;
@@ -1274,11 +1593,11 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
       (rc = t_nvrows.alloc((size_t)T * 4 + 4)) || (rc = t_ncoo.alloc((size_t)T * 4 + 4)))
     return rc;
   hipLaunchKernelGGL(dp_tilecount_kernel, dim3(T), dim3(kBlock), 0, 0, (const Tile *)d_tiles.p, rb,
-                     (const int32_t *)S->lcnt.p, (int32_t *)t_acap.p, (int32_t *)t_nvrows.p, (int32_t *)t_ncoo.p);
+                     (const int32_t *)M->lcnt.p, (int32_t *)t_acap.p, (int32_t *)t_nvrows.p, (int32_t *)t_ncoo.p);
   HIPCHK(hipGetLastError());
   std::vector<int32_t> h_nvrows, h_ncoo;
   if ((rc = dl(h_nvrows, t_nvrows, T)) || (rc = dl(h_ncoo, t_ncoo, T))) return rc;
-  int64_t halo = 0, slices = 0, nsl = 0, nvr = 0, coo = 0;
+  int64_t halo = 0, slices = 0, nsl = 0, nvr = 0, coo = 0, farlen = 0;
   int max_nsl = 1;
   for (int ti = 0; ti < T; ti++) {
     Tile &t = tiles[ti];
@@ -1286,11 +1605,17 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     t.nslices = (t.nvrows + kLanes - 1) / kLanes;
     t.ncoo = h_ncoo[ti];
     t.nfar = t.nfar_low = 0;
+    if (FS.active)
+      for (int r = t.row0 - rb; r < t.row0 - rb + t.nown; r++) {
+        t.nfar_low += FS.h_farL[r];
+        t.nfar += FS.h_farL[r] + FS.h_farU[r];
+      }
     t.halo_off = (int32_t)halo;
     t.slice_base = (int32_t)slices;
     t.slot_off = (int32_t)nsl;
     t.vrow_off = (int32_t)nvr;
-    t.far_off = 0;
+    t.far_off = (int32_t)farlen;
+    farlen += align_up(t.nfar, 256);
     t.coo_off = (int32_t)coo;
     t.aexp = -1000;
     halo += t.nslots - t.nown;
@@ -1300,7 +1625,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     coo += align_up(t.ncoo, 256);
     max_nsl = std::max(max_nsl, (int)t.nslices);
     P.coo_entries += t.ncoo;
-    if (halo > 0x7fffffffLL || nsl > 0x7ffffff0LL || nvr > 0x7ffffff0LL || coo > 0x7fffff00LL) {
+    if (halo > 0x7fffffffLL || nsl > 0x7ffffff0LL || nvr > 0x7ffffff0LL || coo > 0x7fffff00LL || farlen > 0x7fffff00LL) {
       why = "index overflow";
       return kUseHost;
     }
@@ -1320,7 +1645,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   HIPCHK(hipMemsetAsync(m.leadlane.p, 0, (size_t)slices * kLanes + kLanes, 0));
   HIPCHK(hipFuncSetAttribute((const void *)dp_vrows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
   hipLaunchKernelGGL(dp_vrows_kernel, dim3(T), dim3(kBlock), 16384 * 4, 0, (const Tile *)d_tiles.p, rb,
-                     (const int32_t *)S->lcnt.p, (const int32_t *)S->firstcol.p, (const int32_t *)t_acap.p,
+                     (const int32_t *)M->lcnt.p, (const int32_t *)M->firstcol.p, (const int32_t *)t_acap.p,
                      (int32_t *)s_tpos.p, (int32_t *)s_gid.p, (int32_t *)g_tpos.p, (int32_t *)g_key.p,
                      (int32_t *)g_dest.p, (uint32_t *)vr_u_info.p, (int32_t *)vr_u_k0.p, (uint32_t *)m.rowinfo.p,
                      (int32_t *)vk0.p);
@@ -1329,7 +1654,7 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
       (rc = t_rounds.alloc((size_t)T * 4 + 4)))
     return rc;
   hipLaunchKernelGGL(dp_leaders_kernel, dim3(T), dim3(kBlock), (size_t)3 * max_nsl * 4, 0, (const Tile *)d_tiles.p, rb,
-                     (const int32_t *)S->brp.p, (const int32_t *)S->bci.p, (const uint32_t *)m.rowinfo.p,
+                     (const int32_t *)M->brp.p, (const int32_t *)M->bci.p, (const uint32_t *)m.rowinfo.p,
                      (const int32_t *)vk0.p, opt.combine_siblings ? 1 : 0, (SliceMeta *)m.slice_meta.p,
                      (uint8_t *)m.leadlane.p, (long long *)t_len.p, (long long *)t_slen.p, (int32_t *)t_rounds.p,
                      (unsigned long long *)ctr.p, (int *)flags.p);
@@ -1371,8 +1696,8 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     HIPCHK(hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kHashSize * 4));
     const int far_thr = opt.count_far ? std::max(1, opt.far_uses) : 0;
     Tile *dt = (Tile *)d_tiles.p;
-    const int32_t *a_brp = (const int32_t *)S->brp.p, *a_bci = (const int32_t *)S->bci.p, *a_bsrc = S->bsrc(),
-                  *a_dsrc = (const int32_t *)S->dsrc.p, *a_lcnt = (const int32_t *)S->lcnt.p,
+    const int32_t *a_brp = (const int32_t *)M->brp.p, *a_bci = (const int32_t *)M->bci.p, *a_bsrc = M->bsrc(),
+                  *a_dsrc = (const int32_t *)S->dsrc.p, *a_lcnt = (const int32_t *)M->lcnt.p,
                   *a_vk0 = (const int32_t *)vk0.p;
     const uint32_t *a_ri = (const uint32_t *)m.rowinfo.p;
     const SliceMeta *a_sm = (const SliceMeta *)m.slice_meta.p;
@@ -1525,12 +1850,61 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   scatter(m.cvals, cval_map, clen);
   scatter(m.diag, diag_map, (size_t)nvr + 1);
   m.vals.bytes = vlen * sizeof(V);
-  // the far sections are empty (padding only: the kernel's loops never enter them)
-  if ((rc = m.fvals.alloc(256 * sizeof(V))) || (rc = m.frows.alloc(256 * 2)) || (rc = m.fcols.alloc(256 * 4)))
+  // the far sections (without far entries: padding only, the kernel's loops never enter them)
+  const size_t flen = (size_t)farlen + 256;
+  DevBuf fval_map;
+  if ((rc = m.fvals.alloc(flen * sizeof(V))) || (rc = m.frows.alloc(flen * 2)) || (rc = m.fcols.alloc(flen * 4)) ||
+      (rc = fval_map.alloc(flen * 4)))
     return rc;
-  HIPCHK(hipMemsetAsync(m.fvals.p, 0, 256 * sizeof(V), 0));
-  HIPCHK(hipMemsetAsync(m.frows.p, 0, 256 * 2, 0));
-  HIPCHK(hipMemsetAsync(m.fcols.p, 0, 256 * 4, 0));
+  HIPCHK(hipMemsetAsync(m.frows.p, 0, flen * 2, 0));
+  HIPCHK(hipMemsetAsync(m.fcols.p, 0, flen * 4, 0));
+  HIPCHK(hipMemsetAsync(fval_map.p, 0xff, flen * 4, 0));
+  if (FS.active) {
+    const long long Kf = FS.kept;
+    DevBuf PL, PU, upkey, upkey2, uppay, uppay2;
+    if ((rc = PL.alloc(((size_t)rows + 1) * 4)) || (rc = PU.alloc(((size_t)rows + 1) * 4)) ||
+        (rc = upkey.alloc((size_t)Kf * 8 + 8)) || (rc = upkey2.alloc((size_t)Kf * 8 + 8)) ||
+        (rc = uppay.alloc((size_t)Kf * 4 + 4)) || (rc = uppay2.alloc((size_t)Kf * 4 + 4)))
+      return rc;
+    for (DevBuf *pp : {&PL, &PU}) { // exclusive prefixes of farL / farU (their last entry is 0)
+      const int32_t *src = (const int32_t *)(pp == &PL ? FS.farL.p : FS.farU.p);
+      size_t tb = 0;
+      HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, src, (int32_t *)pp->p, rows + 1, (hipStream_t)0));
+      if ((rc = tmp.need(tb))) return rc;
+      tb = tmp.buf.bytes;
+      HIPCHK(hipcub::DeviceScan::ExclusiveSum(tmp.buf.p, tb, src, (int32_t *)pp->p, rows + 1, (hipStream_t)0));
+    }
+    const int32_t *d_perm = perm.empty() ? nullptr : (const int32_t *)S->perm.p;
+    const int gr = (rows + kBlock - 1) / kBlock;
+    const unsigned gk = (unsigned)((Kf + kBlock - 1) / kBlock);
+#define CFS_FAR_ARGS_LOW                                                                                          \
+  rows, rb, (const Tile *)d_tiles.p, (const int32_t *)FS.tor.p, (const int32_t *)S->brp.p, (const int32_t *)S->bci.p, \
+      S->bsrc(), (const uint8_t *)FS.far.p, (const int32_t *)PL.p, d_perm, (uint16_t *)m.frows.p,                 \
+      (int32_t *)m.fcols.p, (int32_t *)fval_map.p, (uint64_t *)upkey.p, (int32_t *)uppay.p
+    if (sizeof(V) == 8) hipLaunchKernelGGL((dp_farlow_kernel<8>), dim3(gr), dim3(kBlock), 0, 0, CFS_FAR_ARGS_LOW);
+    else hipLaunchKernelGGL((dp_farlow_kernel<4>), dim3(gr), dim3(kBlock), 0, 0, CFS_FAR_ARGS_LOW);
+#undef CFS_FAR_ARGS_LOW
+    int end_bit = 32;
+    while (end_bit < 64 && ((unsigned long long)rows >> (end_bit - 32)) != 0) end_bit++;
+    size_t tb = 0;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, (const uint64_t *)upkey.p, (uint64_t *)upkey2.p,
+                                              (const int32_t *)uppay.p, (int32_t *)uppay2.p, (int)Kf, 0, end_bit,
+                                              (hipStream_t)0));
+    if ((rc = tmp.need(tb))) return rc;
+    tb = tmp.buf.bytes;
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(tmp.buf.p, tb, (const uint64_t *)upkey.p, (uint64_t *)upkey2.p,
+                                              (const int32_t *)uppay.p, (int32_t *)uppay2.p, (int)Kf, 0, end_bit,
+                                              (hipStream_t)0));
+#define CFS_FAR_ARGS_UP                                                                                          \
+  Kf, rb, (const Tile *)d_tiles.p, (const int32_t *)FS.tor.p, (const uint64_t *)upkey2.p, (const int32_t *)uppay2.p, \
+      (const int32_t *)PU.p, (uint16_t *)m.frows.p, (int32_t *)m.fcols.p, (int32_t *)fval_map.p
+    if (sizeof(V) == 8) hipLaunchKernelGGL((dp_farup_kernel<8>), dim3(gk), dim3(kBlock), 0, 0, CFS_FAR_ARGS_UP);
+    else hipLaunchKernelGGL((dp_farup_kernel<4>), dim3(gk), dim3(kBlock), 0, 0, CFS_FAR_ARGS_UP);
+#undef CFS_FAR_ARGS_UP
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipDeviceSynchronize()); // the temporaries of this block go out of scope
+  }
+  scatter(m.fvals, fval_map, flen);
   m.has_value_map = opt.keep_value_map;
   if (opt.keep_value_map) { // positions in the caller's values[], as cfs_hip_sym_update_values_* needs them
     auto conv = [&](DevBuf &map, size_t cnt) {
@@ -1544,8 +1918,8 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     m.val_map = std::move(val_map);
     m.cval_map = std::move(cval_map);
     m.diag_map = std::move(diag_map);
-    if ((rc = m.fval_map.alloc(256 * 4))) return rc;
-    HIPCHK(hipMemsetAsync(m.fval_map.p, 0xff, 256 * 4, 0));
+    conv(fval_map, flen);
+    m.fval_map = std::move(fval_map);
   }
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize());
@@ -1582,9 +1956,9 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   P.stream_len = off;
   P.slot_len = soff;
   P.coo_len = coo;
-  P.far_len = 0;
-  P.far_entries = 0;
-  P.far_candidates = (int64_t)h_ctr[C_FARCAND];
+  P.far_len = farlen;
+  P.far_entries = FS.active ? FS.kept : 0;
+  P.far_candidates = opt.hyb ? FS.marked : (int64_t)h_ctr[C_FARCAND];
   P.chained_packets = (int64_t)h_ctr[C_CHAINED];
   P.lane_packets = (int64_t)h_ctr[C_LANEPK];
   P.tiles = tiles;
@@ -1606,10 +1980,23 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   // hand the remaining arrays over
   m.tiles = std::move(d_tiles);
   m.tiles.bytes = (size_t)T * sizeof(Tile);
-  if (!K && cache && cache->valid && cache->device_only && use_clustered && cache->nchunks == nc) {
-    auto keep = std::make_shared<Kept<V>>(); // for tune()'s second window shape
-    keep->in = std::move(in_local);
-    keep->SC = std::move(SC_local);
+  if (cache && cache->rb == rb && cache->re == re) { // for tune()'s later builds of these rows
+    std::shared_ptr<Kept<V>> keep;
+    if (KP) keep = std::static_pointer_cast<Kept<V>>(cache->device_keep);
+    else {
+      keep = std::make_shared<Kept<V>>();
+      keep->in = std::move(in_local);
+      keep->mirror = mirror;
+    }
+    if (!K && have_clusters && SC_local.rows) { // a new clustered placement (whichever order won)
+      keep->SC = std::move(SC_local);
+      keep->has_sc = true;
+      keep->nc = nc;
+      keep->max_slots = L.max_slots;
+      keep->cost_model = opt.cost_model;
+      keep->perm = perm_all;
+      keep->chunk = cchunk;
+    }
     cache->device_keep = keep;
   }
   pt.lap("device: metadata");

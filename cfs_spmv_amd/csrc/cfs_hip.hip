@@ -1982,7 +1982,6 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
       return rc;
     }
   }
-  space.drop(); // release the schedule-space matrix
   // ---- HYB by measurement (Format::sss, Tuning::Aggressive) --------------------------
   // A halo column that its tile uses once costs a slot, a slot-table entry, an x
   // gather, a strip store and a fold entry for one nonzero; as a FAR entry the nonzero
@@ -1993,11 +1992,15 @@ static int sym_create(int n, const int *rowptr, const int *colind, const V *valu
   if (tuning && may_hyb && m->P.far_candidates * 33 >= m->P.nnz_low) {
     cfs_plan::Options po2 = po;
     po2.hyb = true;
-    if ((rc = try_alternative(po2, nullptr, "tile format vs HYB (far entries apart)"))) {
+    int forced = -1; // CFS_HIP_TAKE_HYB=1|0: keep / drop the alternative whatever the clock says (tests)
+    if (const char *e = getenv("CFS_HIP_TAKE_HYB")) forced = atoi(e) != 0 ? 1 : 0;
+    // (the kept upload / schedule space of the builds above serves this one too)
+    if ((rc = try_alternative(po2, &space, "tile format vs HYB (far entries apart)", forced))) {
       delete m;
       return rc;
     }
   }
+  space.drop(); // release the schedule-space matrix / the kept upload
   m->ablate_mode = opt ? (opt->flags & CFS_HIP_FLAG_ABLATE_MASK) : 0;
   *out = m;
   ct.lap("create: measured alternatives");
@@ -2742,6 +2745,14 @@ template <typename V> static int sym_digest(SymMatrix<V> *m, unsigned long long 
   if ((rc = dig(m->slot_exp, m->P.deterministic ? (size_t)nsl * 2 : 0, &w[k++]))) return rc;
   if ((rc = dig(m->send_ptr, m->nsend > 0 ? ((size_t)m->nsend + 1) * 4 : 0, &w[k++]))) return rc;
   if ((rc = dig(m->send_idx, m->nsend > 0 ? (size_t)m->P.send_ptr.back() * 4 : 0, &w[k++]))) return rc;
+  { // far sections (Format::hyb)
+    const size_t fl = (size_t)P.far_len;
+    if ((rc = dig(m->fvals, fl * s, &w[k++]))) return rc;
+    if ((rc = dig(m->frows, fl * 2, &w[k++]))) return rc;
+    if ((rc = dig(m->fcols, fl * 4, &w[k++]))) return rc;
+    if ((rc = dig(m->fval_map, m->has_value_map ? fl * 4 : 0, &w[k++]))) return rc;
+    w[k++] = (unsigned long long)P.far_entries;
+  }
   w[CFS_HIP_DIGEST_WORDS - 1] = m->device_built ? 1ull : 0ull;
   return 0;
 }

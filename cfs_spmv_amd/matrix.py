@@ -54,10 +54,11 @@ def _stream_ptr(stream=None):
 FLAG_SHARD_EXCHANGE = 64  # include/cfs_hip.h: CFS_HIP_FLAG_SHARD_EXCHANGE
 FLAG_KEEP_VALUE_MAP = 2048  # CFS_HIP_FLAG_KEEP_VALUE_MAP
 FLAG_HOST_PLAN = 4096  # CFS_HIP_FLAG_HOST_PLAN: build the schedule with the host builder
-DIGEST_WORDS = 24  # CFS_HIP_DIGEST_WORDS
+DIGEST_WORDS = 28  # CFS_HIP_DIGEST_WORDS
 DIGEST_NAMES = ["tiles", "gfirst", "group_range", "slot_col", "rowinfo", "diag", "slice_meta", "leadlane",
                 "vals", "slots", "cvals", "crows", "ccols", "fold_rec", "fold_idx", "val_map", "cval_map",
-                "diag_map", "window", "slot_exp", "send_ptr", "send_idx", "spare", "device_built"]
+                "diag_map", "window", "slot_exp", "send_ptr", "send_idx", "fvals", "frows", "fcols", "fval_map",
+                "far_entries", "device_built"]
 
 
 def make_options(max_slots=0, max_tile_nnz=0, block_threads=0, flags=0):

@@ -147,9 +147,9 @@ typedef struct {
 #define CFS_HIP_FLAG_KEEP_VALUE_MAP 2048
 /* tune() builds the tile schedule ON THE GPU from one upload of the caller's CSR (split,
  * tile cut, slot tables, virtual rows, leaders, packing: HIP kernels) whenever
- * the options are covered by the device builder -- everything but HYB far entries (and input
- * whose rows are unsorted, hold duplicates or exceed 4096 stored entries: noticed on the GPU,
- * cfs_hip_sym_debug_plan_note says which).  With this flag the host builder
+ * the input is covered by the device builder -- everything but rows that are unsorted, hold
+ * duplicates or exceed 4096 stored entries (noticed on the GPU, cfs_hip_sym_debug_plan_note
+ * says which).  With this flag the host builder
  * (cfs_plan.hpp, OpenMP) is used instead; the two produce the same schedule bit for bit
  * (cfs_hip_sym_debug_digest).                                                          */
 #define CFS_HIP_FLAG_HOST_PLAN 4096
@@ -359,11 +359,12 @@ int cfs_hip_sym_debug_group_features(cfs_hip_sym_t h, long long *out, int capaci
  * their logical lengths, in this order: tiles (aexp masked), launch-slot first tiles, launch-
  * slot tile ranges, slot_col, rowinfo, diag, slice_meta, leadlane, vals, slots, cvals, crows,
  * ccols, fold records, fold remainder lists, val_map, cval_map, diag_map, window / launch shape,
- * slot exponents (deterministic build), send_ptr, send_idx (exchange-form shard) -- 0 when absent.  A
+ * slot exponents (deterministic build), send_ptr, send_idx (exchange-form shard), the far sections
+ * (fvals, frows, fcols, fval_map, count) -- 0 when absent.  A
  * schedule built on the GPU and one built by the host builder for the same matrix and options
  * have equal digests.  words[CFS_HIP_DIGEST_WORDS - 1] = 1 if the handle's schedule was built
  * on the GPU.                                                                           */
-#define CFS_HIP_DIGEST_WORDS 24
+#define CFS_HIP_DIGEST_WORDS 28
 int cfs_hip_sym_debug_digest(cfs_hip_sym_t h, unsigned long long *words, int capacity_words);
 /* why the device builder handed this handle's schedule to the host builder ("" = it built it) */
 int cfs_hip_sym_debug_plan_note(cfs_hip_sym_t h, char *buf, int capacity);

@@ -70,6 +70,56 @@ def test_device_schedule_equals_host_schedule_on_stand_ins(name, scale, dtype):
     H.close()
 
 
+FLAG_HYB, FLAG_NO_REORDER, FLAG_CLUSTER, FLAG_DET = 128, 8, 16, 1024
+
+
+@pytest.mark.parametrize("name,scale,flags,slots", [
+    ("ldoor", 0.05, 0, 0), ("ldoor", 0.3, 0, 0), ("ldoor", 0.1, FLAG_NO_REORDER, 0), ("ldoor", 0.1, FLAG_CLUSTER, 1024),
+    ("unstruct", 0.05, FLAG_NO_REORDER, 0), ("unstruct", 0.05, 0, 0), ("pwtk", 0.2, 0, 512), ("Flan_1565", 0.05, 0, 1024),
+    ("pdb1HYS", 0.3, FLAG_NO_REORDER, 0), ("powerlaw", 0.02, 0, 0), ("ldoor", 0.1, cfs.FLAG_KEEP_VALUE_MAP, 0),
+    ("ldoor", 0.1, FLAG_DET, 0)])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_device_schedule_with_far_entries(name, scale, flags, slots, dtype):
+    """Format::hyb (CFS_HIP_FLAG_HYB): far marks per tile, the second and third cut without them, the
+    marks resolved against the final tiles, the near entries compacted for the tile format and the
+    far sections (own rows' entries, then the mirror images sorted by row and column) -- on the
+    device as on the host, array for array"""
+    import torch
+    n, rp, ci, va, _ = synth.generate(name, scale)
+    va = va.astype(dtype)
+    D, H = _both(n, rp, ci, va, flags=flags | FLAG_HYB, slots=slots)
+    _assert_same(D, H, ("hyb", name, scale, flags, slots, dtype.__name__))
+    sd, sh = D.stats(), H.stats()
+    assert sd["far_entries"] == sh["far_entries"]
+    if name in ("ldoor", "unstruct"):
+        assert sd["far_entries"] > 0 and D.digest()["fcols"] != 0
+    x = torch.from_numpy(synth.make_x(n, 42, dtype)).cuda()
+    yd, yh = torch.empty(n, dtype=x.dtype, device="cuda"), torch.empty(n, dtype=x.dtype, device="cuda")
+    D.dense_vector_multiply(yd, x)
+    H.dense_vector_multiply(yh, x)
+    torch.cuda.synchronize()
+    if flags & FLAG_DET:
+        assert torch.equal(yd, yh)
+    else:
+        tol = 1e-12 if dtype == np.float64 else 1e-5
+        scale_ = torch.maximum(yh.abs(), torch.tensor(1.0, dtype=x.dtype, device="cuda"))
+        assert float(((yd - yh).abs() / scale_).max()) <= 10 * tol
+    D.close()
+    H.close()
+
+
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_device_schedule_of_mirrored_shards_with_far_entries(nranks):
+    n, rp, ci, va, _ = synth.generate("ldoor", 0.1)
+    rs = cfs.balanced_splits(n, rp, ci, nranks)
+    for rank in range(nranks):
+        D, H = _both(n, rp, ci, va, flags=FLAG_HYB, row_splits=rs, rank=rank)
+        _assert_same(D, H, ("hyb mirrored shard", nranks, rank))
+        assert D.stats()["far_entries"] == H.stats()["far_entries"] > 0
+        D.close()
+        H.close()
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_tuned_alternative_reuses_the_kept_placement(dtype, monkeypatch):
     """Tuning::Aggressive builds a second schedule (1 024 threads x 1 per CU, half as many clusters:
@@ -82,6 +132,28 @@ def test_tuned_alternative_reuses_the_kept_placement(dtype, monkeypatch):
     H = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=16 | cfs.FLAG_HOST_PLAN))
     assert D.stats()["block_threads"] == 1024 and H.stats()["block_threads"] == 1024
     _assert_same(D, H, ("tuned alternative", dtype.__name__))
+    D.close()
+    H.close()
+
+
+@pytest.mark.parametrize("name,scale,shape", [("ldoor", 0.3, "512"), ("ldoor", 0.3, "1024"), ("unstruct", 0.1, "512"),
+                                              ("unstruct", 0.1, "1024")])
+def test_tuned_hyb_alternative_reuses_upload_and_clusters(name, scale, shape, monkeypatch):
+    """Tuning::Aggressive may build three schedules of one matrix: two window shapes and Format::hyb
+    for the kept one.  On the device the later builds read the KEPT upload, and the HYB build of
+    the kept shape also the clusters (and their placement) that shape was built from -- whichever
+    row order won.  The choices are pinned (the clock decides otherwise): the result equals the
+    host builder's, array for array"""
+    monkeypatch.setenv("CFS_HIP_SHAPE", shape)
+    monkeypatch.setenv("CFS_HIP_TAKE_HYB", "1")
+    n, rp, ci, va, _ = synth.generate(name, scale)
+    D = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options())
+    H = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=cfs.FLAG_HOST_PLAN))
+    assert D.stats()["block_threads"] == int(shape) == H.stats()["block_threads"]
+    assert D.stats()["far_entries"] == H.stats()["far_entries"]
+    if name == "ldoor":  # (the clustered stand-in has too few single-use halo columns: HYB is not tried)
+        assert D.stats()["far_entries"] > 0
+    _assert_same(D, H, ("tuned + hyb", name, shape))
     D.close()
     H.close()
 
@@ -99,6 +171,8 @@ def test_device_schedule_equals_host_schedule_on_random_matrices(seed):
     flags = int(rng.choice([0, 0, 8, 16]))  # default order choice / natural / clustered
     if seed % 5 == 0:
         flags |= cfs.FLAG_KEEP_VALUE_MAP
+    if seed % 3 == 1:
+        flags |= FLAG_HYB
     try:
         D, H = _both(n, rp, ci, va, flags, slots, block)
     except _lib.CfsHipError as e:
