@@ -745,10 +745,6 @@ __global__ void __launch_bounds__(256)
   send[i] = s;
 }
 
-// first position of block b's 16-bit columns (p0 = its first nonzero): a multiple of 4 (aligned
-// 8-byte loads of four codes), blocks do not overlap
-__host__ __device__ inline size_t csr_col16_offset(int p0, int b) { return ((size_t)p0 + 4 * (size_t)b + 3) & ~(size_t)3; }
-
 // general CSR, streaming form: a workgroup owns a block of consecutive rows whose
 // nonzeros fit its LDS product buffer.  All of the block's colind / values loads
 // are issued at once (16 per thread, non-temporal: the matrix is read once per
@@ -770,7 +766,8 @@ __global__ void __launch_bounds__(256)
                           const int32_t *__restrict__ rowptr,
                           const int32_t *__restrict__ colind, const V *__restrict__ values,
                           const V *__restrict__ x, V *__restrict__ y, int per_xcd,
-                          const uint16_t *__restrict__ col16, const int4 *__restrict__ cbase) {
+                          const uint16_t *__restrict__ col16, const int4 *__restrict__ cbase,
+                          const V *__restrict__ vperm) {
   __shared__ V prod[kCsrNnz];
   __shared__ V part[256];
   __shared__ int32_t rps[kCsrRows + 1];
@@ -799,7 +796,6 @@ __global__ void __launch_bounds__(256)
         const uint32_t k = h >> 14;
         return (k == 0 ? cb4.x : k == 1 ? cb4.y : k == 2 ? cb4.z : cb4.w) + (int)(h & 0x3fffu);
       };
-      const uint16_t *c16 = col16 + csr_col16_offset(p0, b);
       int rpv[kCsrRows / 256 + 1];
 #pragma unroll
       for (int u = 0; u <= kCsrRows / 256; ++u) rpv[u] = rowptr[r0 + min(tid + u * 256, nr)];
@@ -808,19 +804,38 @@ __global__ void __launch_bounds__(256)
         VL vl[PW];
         IL cl[PW];
         const int qmax = max(n - 1, 0) / LW * LW; // first entry of the last vector (the arrays are padded)
-        // (all loads first, the 16-bit codes are decoded only after the last one is on its way)
         if (cb >= 0) {
-          HL hl[PW];
+          // A narrow block reads its OWN copy of the values and its 16-bit column codes, both stored
+          // in the order the lanes consume them (slot b of 4 096 entries each, written once by
+          // cfs_csr_narrow_kernel, zero-padded): the pair a lane loads at position 2 (tid + 256 u)
+          // holds entries 512 u + tid and 512 u + 256 + tid -- wide loads, and still every gather
+          // instruction of a wave walks 64 CONSECUTIVE entries (the pairs of the natural order
+          // walk every second one: twice the cache lines per instruction).  No tail tests: the
+          // padding multiplies 0 by x of the block's first window.
+          const V *vp = vperm + (size_t)b * kCsrNnz;
+          const uint16_t *cp = col16 + (size_t)b * kCsrNnz;
+          const int umax = (n - 1) >> 9;
+          uint32_t hw[PW];
 #pragma unroll
           for (int u = 0; u < PW; ++u) {
-            const int q = min(LW * (tid + u * 256), qmax);
-            vl[u] = __builtin_nontemporal_load(reinterpret_cast<const VL *>(values + p0 + q));
-            hl[u] = __builtin_nontemporal_load(reinterpret_cast<const HL *>(c16 + q));
+            const int q = 2 * (tid + min(u, umax) * 256);
+            vl[u] = __builtin_nontemporal_load(reinterpret_cast<const VL *>(vp + q));
+            hw[u] = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(cp + q));
           }
 #pragma unroll
-          for (int u = 0; u < PW; ++u)
+          for (int u = 0; u <= kCsrRows / 256; ++u)
+            if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
+          V xa[PW], xb[PW];
 #pragma unroll
-            for (int j = 0; j < LW; ++j) cl[u][j] = decode(hl[u][j]);
+          for (int u = 0; u < PW; ++u) {
+            xa[u] = x[decode(hw[u] & 0xffffu)];
+            xb[u] = x[decode(hw[u] >> 16)];
+          }
+#pragma unroll
+          for (int u = 0; u < PW; ++u) {
+            prod[u * 512 + tid] = vl[u][0] * xa[u];
+            prod[u * 512 + 256 + tid] = vl[u][1] * xb[u];
+          }
         } else {
 #pragma unroll
           for (int u = 0; u < PW; ++u) {
@@ -828,24 +843,24 @@ __global__ void __launch_bounds__(256)
             vl[u] = __builtin_nontemporal_load(reinterpret_cast<const VL *>(values + p0 + q));
             cl[u] = __builtin_nontemporal_load(reinterpret_cast<const IL *>(colind + p0 + q));
           }
-        }
 #pragma unroll
-        for (int u = 0; u <= kCsrRows / 256; ++u)
-          if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
-        V xl[PW][LW];
+          for (int u = 0; u <= kCsrRows / 256; ++u)
+            if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
+          V xl[PW][LW];
 #pragma unroll
-        for (int u = 0; u < PW; ++u) {
-          const int q = min(LW * (tid + u * 256), qmax);
+          for (int u = 0; u < PW; ++u) {
+            const int q = min(LW * (tid + u * 256), qmax);
 #pragma unroll
-          for (int j = 0; j < LW; ++j) // (an entry behind the block's last one is not ours: any valid column)
-            xl[u][j] = x[q + j < n ? cl[u][j] : cl[u][0]];
-        }
+            for (int j = 0; j < LW; ++j) // (an entry behind the block's last one is not ours: any valid column)
+              xl[u][j] = x[q + j < n ? cl[u][j] : cl[u][0]];
+          }
 #pragma unroll
-        for (int u = 0; u < PW; ++u) {
-          const int i = LW * (tid + u * 256);
+          for (int u = 0; u < PW; ++u) {
+            const int i = LW * (tid + u * 256);
 #pragma unroll
-          for (int j = 0; j < LW; ++j)
-            if (i + j < n) prod[i + j] = vl[u][j] * xl[u][j];
+            for (int j = 0; j < LW; ++j)
+              if (i + j < n) prod[i + j] = vl[u][j] * xl[u][j];
+          }
         }
       } else {
         V v[PER];
@@ -854,11 +869,7 @@ __global__ void __launch_bounds__(256)
         for (int u = 0; u < PER; ++u) {
           const int q = min(tid + u * 256, max(n, 1) - 1);
           v[u] = __builtin_nontemporal_load(values + p0 + q);
-          c[u] = cb >= 0 ? (int)__builtin_nontemporal_load(c16 + q) : __builtin_nontemporal_load(colind + p0 + q);
-        }
-        if (cb >= 0) {
-#pragma unroll
-          for (int u = 0; u < PER; ++u) c[u] = decode((uint32_t)c[u]);
+          c[u] = __builtin_nontemporal_load(colind + p0 + q);
         }
 #pragma unroll
         for (int u = 0; u <= kCsrRows / 256; ++u)
@@ -903,11 +914,16 @@ __global__ void __launch_bounds__(256)
 // stencil three); a column becomes (window << 14 | offset), the four window starts go to
 // cbase[b].  A block that needs more windows (or one long row) keeps reading colind:
 // cbase[b].x = -1.
+// The codes and a copy of the values of such a block go to slot b (4 096 entries, zero-padded) of
+// col16 / vperm IN THE ORDER THE LANES OF cfs_csr_stream_kernel CONSUME THEM: entry 512 U + 256 h + t
+// of the block at position 512 U + 2 t + h.
 constexpr int kCsrWinBits = 14;
+template <typename V>
 __global__ void __launch_bounds__(256)
     cfs_csr_narrow_kernel(const int32_t *__restrict__ blk_row, int nblocks, const int32_t *__restrict__ rowptr,
-                          const int32_t *__restrict__ colind, uint16_t *__restrict__ col16,
-                          int4 *__restrict__ cbase, unsigned long long *__restrict__ narrow_nnz) {
+                          const int32_t *__restrict__ colind, const V *__restrict__ values,
+                          uint16_t *__restrict__ col16, V *__restrict__ vperm, int4 *__restrict__ cbase,
+                          unsigned long long *__restrict__ narrow_nnz) {
   __shared__ int smin[256];
   const int tid = threadIdx.x;
   constexpr int PER = kCsrNnz / 256, kNone = 0x7fffffff;
@@ -951,17 +967,24 @@ __global__ void __launch_bounds__(256)
       if (narrow) atomicAdd(narrow_nnz, (unsigned long long)n);
     }
     if (narrow) {
-      uint16_t *c16 = col16 + csr_col16_offset(p0, b);
+      uint16_t *c16 = col16 + (size_t)b * kCsrNnz;
+      V *vp = vperm + (size_t)b * kCsrNnz;
 #pragma unroll
-      for (int u = 0; u < PER; ++u)
+      for (int u = 0; u < PER; ++u) {
+        const int pos = (u >> 1) * 512 + 2 * tid + (u & 1);
         if (tid + u * 256 < n) {
           // the LAST window that starts at or below the column (window starts ascend; unused ones repeat)
           int k = 0;
           if (c[u] >= base[1] && base[1] > base[0]) k = 1;
           if (c[u] >= base[2] && base[2] > base[1]) k = 2;
           if (c[u] >= base[3] && base[3] > base[2]) k = 3;
-          c16[tid + u * 256] = (uint16_t)((k << kCsrWinBits) | (c[u] - base[k]));
+          c16[pos] = (uint16_t)((k << kCsrWinBits) | (c[u] - base[k]));
+          vp[pos] = values[p0 + tid + u * 256];
+        } else { // padding: 0 x (x of the first window's first column)
+          c16[pos] = 0;
+          vp[pos] = V(0);
         }
+      }
     }
   }
 }
@@ -1586,7 +1609,7 @@ struct cfs_hip_csr_s {
   int value_bytes = 8, nrows = 0, ncols = 0, nblocks = 0;
   int64_t nnz = 0;
   DevBuf rowptr, colind, values, blk_row;
-  DevBuf col16, cbase; // block form: 16-bit column codes of the narrow blocks, four window starts per block (x = -1: wide)
+  DevBuf col16, cbase, vperm; // block form: 16-bit column codes + values of the narrow blocks in lane order, four window starts per block (x = -1: wide)
   int64_t narrow_nnz = 0;
   DevBuf chunks, longrows; // wave-stream form: chunk descriptors, rows longer than a chunk
   int nchunks = 0, nlong = 0, wave_grid = 0, block_grid = 256 * 8;
@@ -3044,8 +3067,8 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     const char *e16 = getenv("CFS_HIP_CSR_COL16");
     if (m->nblocks > 0 && m->nnz > 0 && !(e16 && atoi(e16) == 0)) {
       DevBuf cnt;
-      if ((rc = m->col16.alloc(((size_t)m->nnz + 4 * (size_t)m->nblocks) * 2 + 64)) || (rc = m->cbase.alloc((size_t)m->nblocks * 16)) ||
-          (rc = cnt.alloc(8))) {
+      if ((rc = m->col16.alloc((size_t)m->nblocks * kCsrNnz * 2 + 64)) || (rc = m->cbase.alloc((size_t)m->nblocks * 16)) ||
+          (rc = m->vperm.alloc((size_t)m->nblocks * kCsrNnz * sizeof(V) + 64)) || (rc = cnt.alloc(8))) {
         delete m;
         return rc;
       }
@@ -3053,10 +3076,10 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
       unsigned long long nn = 0;
       bool ok = hipMemsetAsync(cnt.p, 0, 8, st) == hipSuccess;
       if (ok) {
-        hipLaunchKernelGGL(cfs_csr_narrow_kernel, dim3(std::min(m->nblocks, 4096)), dim3(256), 0, st,
+        hipLaunchKernelGGL((cfs_csr_narrow_kernel<V>), dim3(std::min(m->nblocks, 4096)), dim3(256), 0, st,
                            (const int32_t *)m->blk_row.p, m->nblocks, (const int32_t *)m->rowptr.p,
-                           (const int32_t *)m->colind.p, (uint16_t *)m->col16.p, (int4 *)m->cbase.p,
-                           (unsigned long long *)cnt.p);
+                           (const int32_t *)m->colind.p, (const V *)m->values.p, (uint16_t *)m->col16.p,
+                           (V *)m->vperm.p, (int4 *)m->cbase.p, (unsigned long long *)cnt.p);
         ok = hipGetLastError() == hipSuccess &&
              hipMemcpyAsync(&nn, cnt.p, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
@@ -3066,6 +3089,7 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
       if (!ok || m->narrow_nnz * 2 < m->nnz) {
         m->col16 = DevBuf();
         m->cbase = DevBuf();
+        m->vperm = DevBuf();
         m->narrow_nnz = 0;
       }
       if (getenv("CFS_PLAN_VERBOSE"))
@@ -3200,7 +3224,7 @@ static int csr_launch(cfs_hip_csr_t h, void *y, const void *x, hipStream_t st) {
   hipLaunchKernelGGL((cfs_csr_stream_kernel<V, W>), dim3(grid), dim3(256), 0, st, (const int32_t *)h->blk_row.p, \
                      h->nblocks, (const int32_t *)h->rowptr.p, (const int32_t *)h->colind.p,                \
                      (const V *)h->values.p, (const V *)x, (V *)y, per_xcd, (const uint16_t *)h->col16.p,  \
-                     (const int4 *)h->cbase.p)
+                     (const int4 *)(h->wide == 2 ? h->cbase.p : nullptr), (const V *)h->vperm.p)
     if (h->value_bytes == 8) {
       if (h->wide == 2) CFS_CSR_BLOCK(double, 2);
       else CFS_CSR_BLOCK(double, 1);
@@ -3225,10 +3249,11 @@ int cfs_hip_csr_stats(cfs_hip_csr_t h, int64_t *bytes_streamed, int64_t *narrow_
   if (!h) return set_err(CFS_HIP_ERR_ARG, "null argument");
   const int64_t vb = h->value_bytes, nz = h->nnz;
   int64_t b = nz * vb + ((int64_t)h->nrows + 1) * 4;
-  if (h->block_form) b += h->narrow_nnz * 2 + (nz - h->narrow_nnz) * 4 + (int64_t)h->nblocks * (h->cbase.p ? 20 : 4);
+  const int64_t nar = h->wide == 2 ? h->narrow_nnz : 0;
+  if (h->block_form) b += nar * 2 + (nz - nar) * 4 + (int64_t)h->nblocks * (h->cbase.p ? 20 : 4);
   else b += nz * 4 + (int64_t)h->nchunks * 16;
   if (bytes_streamed) *bytes_streamed = b;
-  if (narrow_nnz) *narrow_nnz = h->block_form ? h->narrow_nnz : 0;
+  if (narrow_nnz) *narrow_nnz = h->block_form && h->wide == 2 ? h->narrow_nnz : 0;
   return 0;
 }
 
