@@ -1,14 +1,18 @@
 """copy the per-config evidence of tools/profile_round.sh from gpurun_out/<round>/<cfg>/ into
 profiles/<round>_<cfg>_* (tracked) and rebuild profiles/hbm_traffic.json, the table bench.py
 reads for roofline.traffic (keyed by workload, validated against the schedule that runs).
-usage: collect_profiles.py r02 flan=Flan_1565:1.0:f64:1 flan_w1024=Flan_1565:1.0:f64:1 pwtk=pwtk:1.0:f64:1 ...
+usage: collect_profiles.py [--merge] r02 flan=Flan_1565:1.0:f64:1 flan_w1024=Flan_1565:1.0:f64:1 pwtk=pwtk:1.0:f64:1 ...
 (several sets may share a key: one entry per schedule the workload was profiled on)"""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1]
+args = [a for a in sys.argv[1:] if a != "--merge"]
+merge = "--merge" in sys.argv[1:]  # keep the table's other keys (only the sets named here were re-taken)
+rnd = args[0]
 table_path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-table = {}
-for arg in sys.argv[2:]:
+table = json.load(open(table_path)) if merge and os.path.exists(table_path) else {}
+for key in {a.split("=")[1] for a in args[1:]}:
+    table.pop(key, None)
+for arg in args[1:]:
     cfg, key = arg.split("=")
     src = os.path.join(ROOT, "gpurun_out", rnd, cfg)
     for name in ("bench.json", "kernel_stats.csv", "pmc_fetch.csv", "pmc_write.csv", "hbm_traffic.json"):
