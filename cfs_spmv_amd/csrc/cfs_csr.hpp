@@ -51,6 +51,10 @@ __global__ void __launch_bounds__(256)
     const int r0 = blk_row[b], r1 = blk_row[b + 1];
     const int p0 = rowptr[r0], p1 = rowptr[r1];
     const int n = p1 - p0;
+    if (n == 0) { // empty rows only: nothing to load (the clamped loads below would read past the last entry)
+      for (int r = r0 + tid; r < r1; r += 256) y[r] = V(0);
+      continue;
+    }
     if (n <= kCsrNnz) {
       const int nr = r1 - r0;
       // a block whose columns fit four windows of 16 384 has them as 16-bit codes (window << 14 |

@@ -265,6 +265,8 @@ struct DevBuf {
     bytes = n;
     n += 64; // padding: clamped / one-past-the-end reads of the kernels stay inside
     HIPCHK(hipMalloc(&p, n));
+    // ... and read zeros: an index read there (an empty row block at the end of colind) must be a valid one
+    HIPCHK(hipMemset((char *)p + bytes, 0, 64));
     return staged_upload(p, src, bytes);
   }
   int alloc(size_t n) {

@@ -223,6 +223,42 @@ def test_csr_block_form_with_narrow_and_wide_row_blocks(col16, monkeypatch):
         G.close()
 
 
+@pytest.mark.parametrize("last_col,narrow", [(65535, True), (65536, False)])
+def test_csr_column_code_window_boundaries(last_col, narrow, monkeypatch):
+    """the 16-bit column codes at their limits: columns 0, 16 383 | 16 384, 32 767 | 32 768, 49 151 |
+    49 152, 65 535 fill four windows of 16 384 to the last offset; one column more (65 536) needs a fifth
+    window and the block keeps its 32-bit columns.  cfs_hip_csr_stats says which, y is right either way"""
+    import ctypes as C
+    import scipy.sparse as sp
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import _lib
+    from oracle import oracle
+    torch = _torch()
+    monkeypatch.setenv("CFS_HIP_CSR_KERNEL", "block")
+    n = 70_000
+    cols = np.array([0, 16383, 16384, 32767, 32768, 49151, 49152, last_col])
+    nrows_used = 40  # one block
+    r = np.repeat(np.arange(nrows_used), cols.size)
+    c = np.tile(cols, nrows_used)
+    rng = np.random.default_rng(9)
+    A = sp.csr_matrix((rng.standard_normal(r.size), (r, c)), shape=(n, n))
+    rp, ci = A.indptr.astype(np.int32), A.indices.astype(np.int32)
+    for dtype in (np.float64, np.float32):
+        v = A.data.astype(dtype)
+        x = rng.standard_normal(n).astype(dtype)
+        G = cfs.CsrMatrix(n, n, rp, ci, v)
+        streamed, nar = C.c_int64(), C.c_int64()
+        _lib.check(_lib.load().cfs_hip_csr_stats(G._h, C.byref(streamed), C.byref(nar)))
+        assert (nar.value == A.nnz) == narrow and nar.value in (0, A.nnz)
+        xd = torch.from_numpy(x).cuda()
+        yd = torch.full((n,), float("nan"), dtype=xd.dtype, device="cuda")
+        G.dense_vector_multiply(yd, xd)
+        torch.cuda.synchronize()
+        y_ld, absrow = oracle.csr_spmv_ld(n, rp, ci, v, x)
+        assert scaled_err(yd.cpu().numpy(), y_ld, absrow) <= TOL[dtype]
+        G.close()
+
+
 @pytest.mark.parametrize("nranks", [2, 4])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 def test_shards_on_one_device(nranks, dtype):
