@@ -19,7 +19,7 @@ INC     := -Iinclude
 all: $(PKG)/libcfs_hip.so $(BUILD)/libsparse.so $(BUILD)/bench_spmv_mmf $(BUILD)/test_spmv_mmf
 
 # kernels + C ABI (also what cfs_spmv_amd/build.py builds)
-$(PKG)/libcfs_hip.so: $(PKG)/csrc/cfs_hip.hip $(PKG)/csrc/cfs_plan.hpp $(PKG)/csrc/cfs_devplan.hpp $(PKG)/csrc/cfs_comm.hpp $(PKG)/csrc/cfs_csr.hpp $(PKG)/csrc/cfs_runtime.hpp include/cfs_hip.h
+$(PKG)/libcfs_hip.so: $(PKG)/csrc/cfs_hip.hip $(PKG)/csrc/cfs_plan.hpp $(PKG)/csrc/cfs_devplan.hpp $(PKG)/csrc/cfs_comm.hpp $(PKG)/csrc/cfs_csr.hpp $(PKG)/csrc/cfs_solver.hpp $(PKG)/csrc/cfs_runtime.hpp include/cfs_hip.h
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -shared -fopenmp $(INC) -I$(PKG)/csrc $< -o $@ -ldl
 
 LIBSRC := src/allocator.cpp src/runtime.cpp src/mmf.cpp src/csr.cpp src/cfs.cpp

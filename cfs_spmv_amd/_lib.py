@@ -53,7 +53,7 @@ SYMBOLS = [
     "cfs_hip_sym_create_shard_f64", "cfs_hip_sym_create_shard_f32",
     "cfs_hip_sym_create_multi_f64", "cfs_hip_sym_create_multi_f32", "cfs_hip_comm_create", "cfs_hip_comm_info", "cfs_hip_comm_destroy", "cfs_hip_comm_reduce_scatter",
     "cfs_hip_comm_allgather", "cfs_hip_comm_wait_consumed", "cfs_hip_sym_num_gpus", "cfs_hip_sym_multi_set_xmode", "cfs_hip_sym_multi_devices", "cfs_hip_sym_balanced_splits", "cfs_hip_sym_destroy", "cfs_hip_sym_update_values_f64", "cfs_hip_sym_update_values_f32", "cfs_hip_sym_spmv",
-    "cfs_hip_sym_spmv_async", "cfs_hip_sym_shard_send_counts", "cfs_hip_sym_shard_send_rows",
+    "cfs_hip_sym_spmv_async", "cfs_hip_sym_cg", "cfs_hip_sym_shard_send_counts", "cfs_hip_sym_shard_send_rows",
     "cfs_hip_sym_shard_set_recv", "cfs_hip_sym_spmv_local_async",
     "cfs_hip_sym_recv_fold_async", "cfs_hip_sym_spmv_phases_async", "cfs_hip_sym_get_stats", "cfs_hip_sym_debug_digest", "cfs_hip_sym_debug_plan_note", "cfs_hip_sym_debug_timeline", "cfs_hip_sym_debug_group_features", "cfs_hip_sym_plan_check_f64",
     "cfs_hip_sym_plan_check_f32", "cfs_hip_sym_plan_send_info_f64", "cfs_hip_csr_create_f64", "cfs_hip_csr_create_f32",
@@ -140,6 +140,8 @@ def load():
     lib.cfs_hip_csr_destroy.argtypes = [vp]
     if hasattr(lib, "cfs_hip_csr_kernel_form"):
         lib.cfs_hip_csr_kernel_form.argtypes = [vp, ip, ip]
+    if hasattr(lib, "cfs_hip_sym_cg"):
+        lib.cfs_hip_sym_cg.argtypes = [vp, vp, vp, C.c_double, C.c_int, C.c_int, ip, C.POINTER(C.c_double), vp]
     if hasattr(lib, "cfs_hip_csr_stats"):
         lib.cfs_hip_csr_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.cfs_hip_event_create.argtypes = [C.POINTER(vp)]

@@ -37,7 +37,7 @@ def hipcc_path():
 def build_hip(force=False):
     out = os.path.join(HERE, "libcfs_hip.so")
     srcs = [os.path.join(CSRC, "cfs_hip.hip"), os.path.join(CSRC, "cfs_plan.hpp"),
-            os.path.join(CSRC, "cfs_devplan.hpp"), os.path.join(CSRC, "cfs_comm.hpp"), os.path.join(CSRC, "cfs_csr.hpp"),
+            os.path.join(CSRC, "cfs_devplan.hpp"), os.path.join(CSRC, "cfs_comm.hpp"), os.path.join(CSRC, "cfs_csr.hpp"), os.path.join(CSRC, "cfs_solver.hpp"),
             os.path.join(CSRC, "cfs_runtime.hpp"), os.path.join(ROOT, "include", "cfs_hip.h")]
     if force or _newer(out, srcs):
         _run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",

@@ -1264,6 +1264,7 @@ template <typename V> struct SymMatrix : cfs_hip_sym_s {
 
 #include "cfs_devplan.hpp" // tune() on the GPU (needs SymMatrix and cfs_value_scatter_kernel)
 #include "cfs_csr.hpp"     // the general CSR path: kernels, handle, create / launch
+#include "cfs_solver.hpp"  // conjugate gradients on resident vectors (a solver-style caller)
 
 
 // ---------------------------------------------------------------------------
@@ -2260,6 +2261,22 @@ int cfs_hip_sym_spmv_async(cfs_hip_sym_t h, void *y, const void *x, void *stream
   if (rc) return rc;
   DeviceGuard g(h->device);
   return h->spmv_local(y, x, nullptr, (hipStream_t)stream);
+}
+
+int cfs_hip_sym_cg(cfs_hip_sym_t h, void *u_dev, const void *b_dev, double tol, int maxiter, int check_every,
+                   int *iterations, double *relres, void *stream) {
+  if (!h || !u_dev || !b_dev) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  if (iterations) *iterations = 0;
+  if (relres) *relres = 0.0;
+  if (!h->send_rows().empty() || dynamic_cast<MultiSym *>(h))
+    return set_err(CFS_HIP_ERR_UNSUPPORTED, "cg: one whole matrix on one device (a sharded loop: cfs_spmv_amd/solver.py)");
+  int rc = check_placement(h, u_dev, b_dev);
+  if (rc) return rc;
+  h->ok_x = h->ok_y = nullptr; // (the iteration's own vectors are library memory on the handle's device)
+  DeviceGuard g(h->device);
+  if (h->value_bytes == 8)
+    return cfs_solver::cg<double>(h, u_dev, b_dev, tol, maxiter, check_every, iterations, relres, (hipStream_t)stream);
+  return cfs_solver::cg<float>(h, u_dev, b_dev, tol, maxiter, check_every, iterations, relres, (hipStream_t)stream);
 }
 
 int cfs_hip_sym_spmv(cfs_hip_sym_t h, void *y, const void *x) {

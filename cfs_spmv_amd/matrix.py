@@ -203,6 +203,15 @@ class SymMatrix:
         """host numpy arrays: the slow staged drop-in path of cfs_hip_sym_spmv"""
         _lib.check(_lib.load().cfs_hip_sym_spmv(self._h, _ptr(y), _ptr(x)))
 
+    def cg(self, u, b, tol=1e-10, maxiter=1000, check_every=8, stream=None):
+        """conjugate gradients inside the library (cfs_hip_sym_cg): u (device tensor) holds the
+        first guess and receives the solution of A u = b; no host round trip inside the loop.
+        Returns (iterations, ||b - A u|| / ||b||)."""
+        it, res = C.c_int(), C.c_double()
+        _lib.check(_lib.load().cfs_hip_sym_cg(self._h, _ptr(u), _ptr(b), float(tol), int(maxiter), int(check_every),
+                                              C.byref(it), C.byref(res), _stream_ptr(stream)))
+        return it.value, res.value
+
     # -- sharded operation --
     def send_counts(self):
         out = np.zeros(self.nranks, dtype=np.int32)

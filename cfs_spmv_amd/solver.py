@@ -36,6 +36,17 @@ def cg(A, b, tol=1e-10, maxiter=1000, x0=None):
     return u, it, res
 
 
+def cg_native(A, b, tol=1e-10, maxiter=1000, x0=None, check_every=8):
+    """the same iteration inside the library (cfs_hip_sym_cg, cfs_spmv_amd/csrc/cfs_solver.hpp):
+    five launches per iteration and no host round trip -- the loop above reads two dot products
+    on the host per iteration, a stream synchronisation each.  Returns (u, iterations, relative
+    residual), like cg()."""
+    import torch
+    u = torch.zeros_like(b) if x0 is None else x0.clone()
+    it, res = A.cg(u, b, tol=tol, maxiter=maxiter, check_every=check_every)
+    return u, it, res
+
+
 def cg_sharded(S, row_splits, b_block, tol=1e-10, maxiter=1000):
     """the same iteration over 1-D row blocks (cfs_spmv_amd.dist.ShardedSym): every
     rank keeps its block of u, r, q and a full replica of the search direction p,

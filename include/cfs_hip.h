@@ -245,6 +245,19 @@ int cfs_hip_sym_update_values_f32(cfs_hip_sym_t h, const float *values, long lon
  *                         (a hipStream_t; NULL = HIP's null stream), returns
  *                         immediately.                                       */
 int cfs_hip_sym_spmv(cfs_hip_sym_t h, void *y, const void *x);
+/* A solver-style caller of the path, native (no counterpart in the reference: its only callers
+ * are a benchmark loop and a self-check with a fixed x, bench/bench_spmv_mmf.cpp:139-173):
+ * conjugate gradients for A u = b on RESIDENT vectors of a symmetric positive definite matrix.
+ * u_dev: in = first guess, out = solution; b_dev: right-hand side; both device pointers of the
+ * handle's device and value type, 16-byte aligned.  An iteration is five launches on `stream` -- the SpMV (two),
+ * p.q, the fused update of u and r with r.r, the new direction -- with every scalar in device
+ * memory: no host round trip inside the loop; the host reads the convergence flag every
+ * `check_every` iterations (<= 0: 8; at most 16).  Stops when ||r|| <= tol ||b|| (the recurrence's r) or after
+ * maxiter iterations; *iterations = iterations done, *relres = ||b - A u|| / ||b|| RECOMPUTED from
+ * the returned u.  Dot products are accumulated in fp64.  Returns after the result is complete.
+ * One whole matrix on one device (not a shard, not a multi-device handle).                    */
+int cfs_hip_sym_cg(cfs_hip_sym_t h, void *u_dev, const void *b_dev, double tol, int maxiter, int check_every,
+                   int *iterations, double *relres, void *stream);
 int cfs_hip_sym_spmv_async(cfs_hip_sym_t h, void *y_dev, const void *x_dev,
                            void *stream);
 

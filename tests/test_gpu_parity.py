@@ -414,6 +414,40 @@ def test_cg_solver_loop_on_the_gpu():
     A.close()
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_native_cg_matches_the_host_driven_loop(dtype):
+    """cfs_hip_sym_cg: the whole iteration behind the C ABI (five launches, scalars in device memory,
+    the host looks at a flag every few iterations) against the torch-driven loop and a direct solve"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    import cfs_spmv_amd as cfs
+    from cfs_spmv_amd import synth
+    from cfs_spmv_amd.solver import cg, cg_native
+    torch = _torch()
+    n, rp, ci, va, _ = synth.generate("pwtk", 0.05)
+    va = va.astype(dtype)
+    A = cfs.SymMatrix(n, rp, ci, va)
+    b = synth.make_x(n, 11, dtype)
+    bd = torch.from_numpy(b).cuda()
+    tol = 1e-11 if dtype == np.float64 else 2e-5
+    u1, it1, res1 = cg(A, bd, tol=tol, maxiter=500)
+    for check_every in (1, 8, 1000):
+        u2, it2, res2 = cg_native(A, bd, tol=tol, maxiter=500, check_every=check_every)
+        torch.cuda.synchronize()
+        assert 0 < it2 < 500 and abs(it2 - it1) <= 2, (it1, it2, check_every)
+        assert res2 <= 10 * tol, (res1, res2)
+    u_ref = spl.spsolve(sp.csc_matrix(sp.csr_matrix((va.astype(np.float64), ci, rp), shape=(n, n))), b.astype(np.float64))
+    lim = 1e-9 if dtype == np.float64 else 2e-3
+    assert np.max(np.abs(u2.cpu().numpy() - u_ref)) <= lim * np.max(np.abs(u_ref))
+    # the iteration limit: stops there, reports the residual it reached
+    u3, it3, res3 = cg_native(A, bd, tol=tol, maxiter=3)
+    assert it3 == 3 and res3 > tol
+    # a first guess that already solves the system: no iteration
+    u4, it4, res4 = cg_native(A, bd, tol=tol, maxiter=500, x0=u2)
+    assert it4 <= 1 and res4 <= 10 * tol
+    A.close()
+
+
 def _fallback_worker(rank, world, port, q):
     try:
         import os, sys
