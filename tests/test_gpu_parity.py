@@ -446,6 +446,14 @@ def test_native_cg_matches_the_host_driven_loop(dtype):
     u4, it4, res4 = cg_native(A, bd, tol=tol, maxiter=500, x0=u2)
     assert it4 <= 1 and res4 <= 10 * tol
     A.close()
+    # with a deterministic handle the whole solve is bit-reproducible: the scalars are sums of
+    # per-workgroup partial sums in a fixed order, not atomics
+    D = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=1024))
+    ua, ita, _ = cg_native(D, bd, tol=tol, maxiter=60)
+    ub, itb, _ = cg_native(D, bd, tol=tol, maxiter=60)
+    torch.cuda.synchronize()
+    assert ita == itb and torch.equal(ua, ub)
+    D.close()
 
 
 def _fallback_worker(rank, world, port, q):
