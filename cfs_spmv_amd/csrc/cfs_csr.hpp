@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(256)
                           const int32_t *__restrict__ colind, const V *__restrict__ values,
                           const V *__restrict__ x, V *__restrict__ y, int per_xcd,
                           const uint16_t *__restrict__ col16, const int4 *__restrict__ cbase,
-                          const V *__restrict__ vperm) {
+                          const V *__restrict__ vperm, const int32_t *__restrict__ col32) {
   __shared__ V prod[kCsrNnz];
   __shared__ V part[256];
   __shared__ int32_t rps[kCsrRows + 1];
@@ -99,6 +99,31 @@ __global__ void __launch_bounds__(256)
           for (int u = 0; u < PW; ++u) {
             xa[u] = x[decode(hw[u] & 0xffffu)];
             xb[u] = x[decode(hw[u] >> 16)];
+          }
+#pragma unroll
+          for (int u = 0; u < PW; ++u) {
+            prod[u * 512 + tid] = vl[u][0] * xa[u];
+            prod[u * 512 + 256 + tid] = vl[u][1] * xb[u];
+          }
+        } else if (cb == -2) {
+          // a block that needs more than four windows: the same lane order, 32-bit columns (col32)
+          const V *vp = vperm + (size_t)b * kCsrNnz;
+          const int32_t *cp = col32 + (size_t)b * kCsrNnz;
+          const int umax = (n - 1) >> 9;
+#pragma unroll
+          for (int u = 0; u < PW; ++u) {
+            const int q = 2 * (tid + min(u, umax) * 256);
+            vl[u] = __builtin_nontemporal_load(reinterpret_cast<const VL *>(vp + q));
+            cl[u] = __builtin_nontemporal_load(reinterpret_cast<const IL *>(cp + q));
+          }
+#pragma unroll
+          for (int u = 0; u <= kCsrRows / 256; ++u)
+            if (tid + u * 256 <= nr) rps[tid + u * 256] = rpv[u] - p0;
+          V xa[PW], xb[PW];
+#pragma unroll
+          for (int u = 0; u < PW; ++u) {
+            xa[u] = x[cl[u][0]];
+            xb[u] = x[cl[u][1]];
           }
 #pragma unroll
           for (int u = 0; u < PW; ++u) {
@@ -192,7 +217,7 @@ __global__ void __launch_bounds__(256)
     cfs_csr_narrow_kernel(const int32_t *__restrict__ blk_row, int nblocks, const int32_t *__restrict__ rowptr,
                           const int32_t *__restrict__ colind, const V *__restrict__ values,
                           uint16_t *__restrict__ col16, V *__restrict__ vperm, int4 *__restrict__ cbase,
-                          unsigned long long *__restrict__ narrow_nnz) {
+                          unsigned long long *__restrict__ narrow_nnz, int32_t *__restrict__ col32) {
   __shared__ int smin[256];
   const int tid = threadIdx.x;
   constexpr int PER = kCsrNnz / 256, kNone = 0x7fffffff;
@@ -232,8 +257,10 @@ __global__ void __launch_bounds__(256)
     for (int u = 0; u < PER; ++u) left |= (c[u] != kNone && c[u] >= bound) ? 1 : 0;
     const bool narrow = __syncthreads_or(left) == 0 && base[0] >= 0;
     if (tid == 0) {
-      cbase[b] = narrow ? make_int4(base[0], base[1], base[2], base[3]) : make_int4(-1, 0, 0, 0);
+      // (x = -2: more than four windows -- lane order too, with 32-bit columns)
+      cbase[b] = narrow ? make_int4(base[0], base[1], base[2], base[3]) : make_int4(col32 ? -2 : -1, 0, 0, 0);
       if (narrow) atomicAdd(narrow_nnz, (unsigned long long)n);
+      else if (col32) atomicAdd(narrow_nnz + 1, (unsigned long long)n);
     }
     if (narrow) {
       uint16_t *c16 = col16 + (size_t)b * kCsrNnz;
@@ -253,6 +280,16 @@ __global__ void __launch_bounds__(256)
           c16[pos] = 0;
           vp[pos] = V(0);
         }
+      }
+    } else if (col32) {
+      int32_t *c32 = col32 + (size_t)b * kCsrNnz;
+      V *vp = vperm + (size_t)b * kCsrNnz;
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int pos = (u >> 1) * 512 + 2 * tid + (u & 1);
+        const bool in = tid + u * 256 < n;
+        c32[pos] = in ? c[u] : base[0]; // padding: 0 x (x of the block's smallest column)
+        vp[pos] = in ? values[p0 + tid + u * 256] : V(0);
       }
     }
   }
@@ -361,7 +398,8 @@ struct cfs_hip_csr_s {
   int64_t nnz = 0;
   DevBuf rowptr, colind, values, blk_row;
   DevBuf col16, cbase, vperm; // block form: 16-bit column codes + values of the narrow blocks in lane order, four window starts per block (x = -1: wide)
-  int64_t narrow_nnz = 0;
+  int64_t narrow_nnz = 0, wide_lane_nnz = 0; // nonzeros of narrow blocks / of wide blocks kept in lane order
+  DevBuf col32;                             // 32-bit columns of the wide blocks, lane order
   DevBuf chunks, longrows; // wave-stream form: chunk descriptors, rows longer than a chunk
   int nchunks = 0, nlong = 0, wave_grid = 0, block_grid = 256 * 8;
   bool xcd_map = true;
@@ -411,33 +449,41 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     if (m->nblocks > 0 && m->nnz > 0 && !(e16 && atoi(e16) == 0)) {
       DevBuf cnt;
       if ((rc = m->col16.alloc((size_t)m->nblocks * kCsrNnz * 2 + 64)) || (rc = m->cbase.alloc((size_t)m->nblocks * 16)) ||
-          (rc = m->vperm.alloc((size_t)m->nblocks * kCsrNnz * sizeof(V) + 64)) || (rc = cnt.alloc(8))) {
+          (rc = m->vperm.alloc((size_t)m->nblocks * kCsrNnz * sizeof(V) + 64)) ||
+          (rc = m->col32.alloc((size_t)m->nblocks * kCsrNnz * 4 + 64)) || (rc = cnt.alloc(16))) {
         delete m;
         return rc;
       }
       hipStream_t st = cfs_rt::home_stream();
-      unsigned long long nn = 0;
-      bool ok = hipMemsetAsync(cnt.p, 0, 8, st) == hipSuccess;
+      const char *e32 = getenv("CFS_HIP_CSR_LANE32"); // 0: blocks with 32-bit columns stay in natural order (A/B)
+      const bool lane32 = !(e32 && atoi(e32) == 0);
+      unsigned long long nn[2] = {0, 0};
+      bool ok = hipMemsetAsync(cnt.p, 0, 16, st) == hipSuccess;
       if (ok) {
         hipLaunchKernelGGL((cfs_csr_narrow_kernel<V>), dim3(std::min(m->nblocks, 4096)), dim3(256), 0, st,
                            (const int32_t *)m->blk_row.p, m->nblocks, (const int32_t *)m->rowptr.p,
                            (const int32_t *)m->colind.p, (const V *)m->values.p, (uint16_t *)m->col16.p,
-                           (V *)m->vperm.p, (int4 *)m->cbase.p, (unsigned long long *)cnt.p);
+                           (V *)m->vperm.p, (int4 *)m->cbase.p, (unsigned long long *)cnt.p,
+                           lane32 ? (int32_t *)m->col32.p : (int32_t *)nullptr);
         ok = hipGetLastError() == hipSuccess &&
-             hipMemcpyAsync(&nn, cnt.p, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+             hipMemcpyAsync(nn, cnt.p, 16, hipMemcpyDeviceToHost, st) == hipSuccess &&
              hipStreamSynchronize(st) == hipSuccess;
       }
-      m->narrow_nnz = (int64_t)nn;
-      // not worth the second column array when few blocks qualify
-      if (!ok || m->narrow_nnz * 2 < m->nnz) {
+      m->narrow_nnz = (int64_t)nn[0];
+      m->wide_lane_nnz = (int64_t)nn[1];
+      if (!ok) {
         m->col16 = DevBuf();
         m->cbase = DevBuf();
         m->vperm = DevBuf();
-        m->narrow_nnz = 0;
+        m->col32 = DevBuf();
+        m->narrow_nnz = m->wide_lane_nnz = 0;
+      } else { // (an array no block uses is not kept)
+        if (m->narrow_nnz == 0) m->col16 = DevBuf();
+        if (m->wide_lane_nnz == 0) m->col32 = DevBuf();
       }
       if (getenv("CFS_PLAN_VERBOSE"))
-        fprintf(stderr, "[cfs_hip] general CSR: %lld of %lld nonzeros in blocks with 16-bit columns\n",
-                (long long)m->narrow_nnz, (long long)m->nnz);
+        fprintf(stderr, "[cfs_hip] general CSR: %lld of %lld nonzeros in blocks with 16-bit columns, %lld in lane-ordered blocks with 32-bit columns\n",
+                (long long)m->narrow_nnz, (long long)m->nnz, (long long)m->wide_lane_nnz);
     }
   }
   { // wave-stream form: chunks of whole rows (<= kCwNnz nonzeros, <= kCwRows rows); longer rows apart
@@ -551,7 +597,8 @@ static int csr_launch(cfs_hip_csr_t h, void *y, const void *x, hipStream_t st) {
   hipLaunchKernelGGL((cfs_csr_stream_kernel<V, W>), dim3(grid), dim3(256), 0, st, (const int32_t *)h->blk_row.p, \
                      h->nblocks, (const int32_t *)h->rowptr.p, (const int32_t *)h->colind.p,                \
                      (const V *)h->values.p, (const V *)x, (V *)y, per_xcd, (const uint16_t *)h->col16.p,  \
-                     (const int4 *)(h->wide == 2 ? h->cbase.p : nullptr), (const V *)h->vperm.p)
+                     (const int4 *)(h->wide == 2 ? h->cbase.p : nullptr), (const V *)h->vperm.p,                \
+                     (const int32_t *)h->col32.p)
     if (h->value_bytes == 8) {
       if (h->wide == 2) CFS_CSR_BLOCK(double, 2);
       else CFS_CSR_BLOCK(double, 1);

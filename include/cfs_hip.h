@@ -437,8 +437,9 @@ int cfs_hip_csr_destroy(cfs_hip_csr_t h);
 int cfs_hip_csr_kernel_form(cfs_hip_csr_t h, int *form, int *measured);
 /* The block form reads 16-bit column codes (2 bytes per nonzero instead of 4) in every row
  * block whose columns fit into four windows of 16 384 columns (window << 14 | offset; banded
- * matrices, 3-D stencils; written once, on the device, when the handle is created; kept when
- * at least half of the nonzeros qualify; CFS_HIP_CSR_COL16=0: never), and
+ * matrices, 3-D stencils; written once, on the device, when the handle is created;
+ * CFS_HIP_CSR_COL16=0: never); the codes -- or, for a block that needs more windows, its 32-bit
+ * columns -- and a copy of the block's values are stored in the order the lanes consume them; and
  * both forms hand the k-th eighth of the matrix to XCD k (CFS_HIP_CSR_XCD=0: round robin).
  * bytes_streamed = bytes one SpMV of the kept form reads from the handle's arrays;
  * narrow_nnz = nonzeros stored with 16-bit columns.                                          */
