@@ -2268,8 +2268,8 @@ int cfs_hip_sym_cg(cfs_hip_sym_t h, void *u_dev, const void *b_dev, double tol, 
   if (!h || !u_dev || !b_dev) return set_err(CFS_HIP_ERR_ARG, "null argument");
   if (iterations) *iterations = 0;
   if (relres) *relres = 0.0;
-  if (!h->send_rows().empty() || dynamic_cast<MultiSym *>(h))
-    return set_err(CFS_HIP_ERR_UNSUPPORTED, "cg: one whole matrix on one device (a sharded loop: cfs_spmv_amd/solver.py)");
+  if (!h->send_rows().empty())
+    return set_err(CFS_HIP_ERR_UNSUPPORTED, "cg: a handle of the whole matrix (a loop over shards of several processes: cfs_spmv_amd/solver.py)");
   int rc = check_placement(h, u_dev, b_dev);
   if (rc) return rc;
   h->ok_x = h->ok_y = nullptr; // (the iteration's own vectors are library memory on the handle's device)

@@ -255,7 +255,8 @@ int cfs_hip_sym_spmv(cfs_hip_sym_t h, void *y, const void *x);
  * `check_every` iterations (<= 0: 8; at most 16).  Stops when ||r|| <= tol ||b|| (the recurrence's r) or after
  * maxiter iterations; *iterations = iterations done, *relres = ||b - A u|| / ||b|| RECOMPUTED from
  * the returned u.  Dot products are accumulated in fp64.  Returns after the result is complete.
- * One whole matrix on one device (not a shard, not a multi-device handle).                    */
+ * A handle of the whole matrix: one device, or a multi-device handle (cfs_hip_sym_create_multi_*:
+ * the vector kernels run on its home device, the products on all of them); not a shard.       */
 int cfs_hip_sym_cg(cfs_hip_sym_t h, void *u_dev, const void *b_dev, double tol, int maxiter, int check_every,
                    int *iterations, double *relres, void *stream);
 int cfs_hip_sym_spmv_async(cfs_hip_sym_t h, void *y_dev, const void *x_dev,

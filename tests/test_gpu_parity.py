@@ -446,6 +446,14 @@ def test_native_cg_matches_the_host_driven_loop(dtype):
     u4, it4, res4 = cg_native(A, bd, tol=tol, maxiter=500, x0=u2)
     assert it4 <= 1 and res4 <= 10 * tol
     A.close()
+    # a multi-device handle (two shards, here on one device): the products on the shards' streams,
+    # the vector kernels on the caller's
+    M = cfs.SymMatrix(n, rp, ci, va, ngpus=2)
+    um, itm, resm = cg_native(M, bd, tol=tol, maxiter=500)
+    torch.cuda.synchronize()
+    assert abs(itm - it1) <= 2 and resm <= 10 * tol
+    assert np.max(np.abs(um.cpu().numpy() - u_ref)) <= lim * np.max(np.abs(u_ref))
+    M.close()
     # with a deterministic handle the whole solve is bit-reproducible: the scalars are sums of
     # per-workgroup partial sums in a fixed order, not atomics
     D = cfs.SymMatrix(n, rp, ci, va, options=cfs.make_options(flags=1024))
