@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(kThreads)
   }
   for (long long i = nv * W + t0; i < n; i += stride) p[i] = (V)((double)r[i] + beta * (double)p[i]);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
-    ic[I_ITER] = it + 1;
+    ic[I_ITER] += 1; // (counted on the device: a replayed graph passes the same `it` again, only its parity matters)
     // (!(x > y): a NaN residual also ends the iteration)
     if (!(rrn > stop)) ic[I_DONE] = 1;
   }
@@ -194,6 +194,8 @@ int cg(Handle *h, void *u_dev, const void *b_dev, double tol, int maxiter, int c
   // (more than ~100 launches enqueued ahead of the GPU make the runtime stall: pwtk stand-in, 64
   // iterations = 320 launches between two looks, 187 us per iteration instead of 32)
   check_every = std::min(check_every, 16);
+  const char *eg = getenv("CFS_HIP_CG_GRAPH");
+  const bool use_graph = eg && atoi(eg) != 0;
   if ((((uintptr_t)u_dev) | ((uintptr_t)b_dev)) & 15)
     return cfs_rt::set_err(CFS_HIP_ERR_ARG, "cg: u and b must be 16-byte aligned");
   V *u = (V *)u_dev;
@@ -230,16 +232,53 @@ int cg(Handle *h, void *u_dev, const void *b_dev, double tol, int maxiter, int c
   bool done = !(rr0 > stop); // the first guess already solves it (or b = 0)
   int host_ic[I_COUNT] = {0, 0};
   int it = 0;
+  auto iteration = [&](int k) -> int {
+    int r2 = h->spmv_local(q, p, nullptr, st);
+    if (r2) return r2;
+    hipLaunchKernelGGL((cg_pq_kernel<V>), dim3(kGrid), dim3(kThreads), 0, st, (const V *)p, (const V *)q, n, part,
+                       (const int *)ic);
+    hipLaunchKernelGGL((cg_update_kernel<V>), dim3(kGrid), dim3(kThreads), 0, st, u, r, (const V *)p, (const V *)q, n,
+                       part, (const int *)ic, k);
+    hipLaunchKernelGGL((cg_direction_kernel<V>), dim3(kGrid), dim3(kThreads), 0, st, p, (const V *)r, n,
+                       (const double *)part, ic, k, stop);
+    return 0;
+  };
+  // CFS_HIP_CG_GRAPH=1: two iterations (both parities) captured once and replayed as one graph launch.
+  // Measured and NOT the default: the replay is 3-10 % slower than ten plain launches (pwtk stand-in
+  // 34.2 against 31.1 us per iteration, ldoor 91 / 87, Flan 145 / 142) -- as for the SpMV's two launches
+  // alone; the host enqueues plain launches faster than the GPU retires them anyway.
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  struct GraphGuard {
+    hipGraph_t &g;
+    hipGraphExec_t &e;
+    ~GraphGuard() {
+      if (e) (void)hipGraphExecDestroy(e);
+      if (g) (void)hipGraphDestroy(g);
+    }
+  } graph_guard{graph, gexec};
+  if (use_graph && !done && maxiter >= 2 && st != nullptr) {
+    bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+    if (ok) {
+      const int r0 = iteration(0), r1 = r0 ? r0 : iteration(1);
+      ok = hipStreamEndCapture(st, &graph) == hipSuccess && !r1 && graph &&
+           hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      gexec = nullptr;
+    }
+  }
   while (!done && it < maxiter) {
     const int until = std::min(maxiter, it + check_every);
-    for (; it < until; ++it) {
-      if ((rc = h->spmv_local(q, p, nullptr, st))) return rc;
-      hipLaunchKernelGGL((cg_pq_kernel<V>), dim3(kGrid), dim3(kThreads), 0, st, (const V *)p, (const V *)q, n, part,
-                         (const int *)ic);
-      hipLaunchKernelGGL((cg_update_kernel<V>), dim3(kGrid), dim3(kThreads), 0, st, u, r, (const V *)p, (const V *)q, n,
-                         part, (const int *)ic, it);
-      hipLaunchKernelGGL((cg_direction_kernel<V>), dim3(kGrid), dim3(kThreads), 0, st, p, (const V *)r, n,
-                         (const double *)part, ic, it, stop);
+    while (it < until) {
+      if (gexec && (it & 1) == 0 && it + 2 <= until) {
+        HIPCHK(hipGraphLaunch(gexec, st));
+        it += 2;
+      } else {
+        if ((rc = iteration(it))) return rc;
+        ++it;
+      }
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(host_ic, ic, sizeof host_ic, hipMemcpyDeviceToHost, st));

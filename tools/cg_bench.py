@@ -27,7 +27,18 @@ for spec in (sys.argv[1:] or ["pwtk", "ldoor", "Flan_1565"]):
     spmv_us = (time.perf_counter() - t0) / 200 * 1e6
     K = 200
     res = {"n": n, "spmv_us": round(spmv_us, 2)}
+    side = torch.cuda.Stream()  # (a stream capture needs a stream of its own: CFS_HIP_CG_GRAPH=1)
+
+    def on_side(f):
+        def run():
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                out = f()
+            torch.cuda.current_stream().wait_stream(side)
+            return out
+        return run
     for label, fn in (("torch_loop", lambda: cg(A, b, tol=0.0, maxiter=K)),
+                      ("native_side_stream", on_side(lambda: cg_native(A, b, tol=0.0, maxiter=K, check_every=16))),
                       ("native_check8", lambda: cg_native(A, b, tol=0.0, maxiter=K, check_every=8)),
                       ("native_check16", lambda: cg_native(A, b, tol=0.0, maxiter=K, check_every=16))):
         fn()
