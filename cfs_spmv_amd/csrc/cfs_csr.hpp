@@ -448,17 +448,17 @@ static int csr_create(int nrows, int ncols, const int *rowptr, const int *colind
     const char *e16 = getenv("CFS_HIP_CSR_COL16");
     if (m->nblocks > 0 && m->nnz > 0 && !(e16 && atoi(e16) == 0)) {
       DevBuf cnt;
-      if ((rc = m->col16.alloc((size_t)m->nblocks * kCsrNnz * 2 + 64)) || (rc = m->cbase.alloc((size_t)m->nblocks * 16)) ||
-          (rc = m->vperm.alloc((size_t)m->nblocks * kCsrNnz * sizeof(V) + 64)) ||
-          (rc = m->col32.alloc((size_t)m->nblocks * kCsrNnz * 4 + 64)) || (rc = cnt.alloc(16))) {
-        delete m;
-        return rc;
-      }
+      // (the lane-ordered copies are an optimisation: without the memory for them the handle works
+      // from the natural-order arrays alone)
+      const bool have = !m->col16.alloc((size_t)m->nblocks * kCsrNnz * 2 + 64) && !m->cbase.alloc((size_t)m->nblocks * 16) &&
+                        !m->vperm.alloc((size_t)m->nblocks * kCsrNnz * sizeof(V) + 64) &&
+                        !m->col32.alloc((size_t)m->nblocks * kCsrNnz * 4 + 64) && !cnt.alloc(16);
+      if (!have) (void)hipGetLastError();
       hipStream_t st = cfs_rt::home_stream();
       const char *e32 = getenv("CFS_HIP_CSR_LANE32"); // 0: blocks with 32-bit columns stay in natural order (A/B)
       const bool lane32 = !(e32 && atoi(e32) == 0);
       unsigned long long nn[2] = {0, 0};
-      bool ok = hipMemsetAsync(cnt.p, 0, 16, st) == hipSuccess;
+      bool ok = have && hipMemsetAsync(cnt.p, 0, 16, st) == hipSuccess;
       if (ok) {
         hipLaunchKernelGGL((cfs_csr_narrow_kernel<V>), dim3(std::min(m->nblocks, 4096)), dim3(256), 0, st,
                            (const int32_t *)m->blk_row.p, m->nblocks, (const int32_t *)m->rowptr.p,
