@@ -1425,6 +1425,44 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   Sched SC_local, SN, *S = nullptr;
   Input<V> &in = KP ? KP->in : in_local;
   Sched &SC = K ? K->SC : SC_local;
+  auto natural_chunks = [&](Sched &X) { // cfs_plan::Builder::cut_chunks
+    X.chunk.assign((size_t)nc + 1, re);
+    X.chunk[0] = rb;
+    const std::vector<double> share = L.shares(opt);
+    std::vector<double> cum((size_t)nc + 1, 0.0);
+    for (int c = 0; c < nc; c++) cum[c + 1] = cum[c] + share[c];
+    for (int c = 1; c < nc; c++) {
+      const int64_t target = (int64_t)((double)X.cost[rows] * (cum[c] / cum[nc]));
+      int r = (int)(std::lower_bound(X.cost.begin(), X.cost.end(), target) - X.cost.begin());
+      if (r > rows) r = rows;
+      if (rb + r < X.chunk[c - 1]) r = X.chunk[c - 1] - rb;
+      X.chunk[c] = rb + r;
+    }
+    X.chunk[nc] = re;
+  };
+  FarState FC, FN; // Format::hyb: the far entries of either order
+  auto cut_with = [&](Sched &X, FarState &F, bool natural, Scratch &tmp_, DevBuf &flags_, DevBuf &ctr_,
+                      std::string &why_) -> int {
+    row_costs<V>(X, nullptr, nullptr); // (a kept placement may hold the costs of an earlier HYB build)
+    if (natural) natural_chunks(X);
+    if (!opt.hyb) return cut_tiles<V>(X, L, opt, flags_, why_);
+    return hyb_cut<V>(X, F, L, opt, natural, natural_chunks, tmp_, flags_, ctr_, why_);
+  };
+  auto cut = [&](Sched &X, FarState &F, bool natural) -> int { return cut_with(X, F, natural, tmp, flags, ctr, why); };
+
+  // The natural order needs no clusters: when the host is about to sweep for them (tens to hundreds of
+  // milliseconds, nothing for the device to do), the uploader thread goes on to place and cut the natural
+  // order -- with buffers of its own -- as soon as the matrix is on the device.
+  const bool will_sweep = may_cluster && !same_clusters &&
+                          !(cache && cache->valid && cache->rb == rb && cache->re == re && cache->nchunks == 2 * nc &&
+                            (pair_clusters || !cache->device_only));
+  const bool nat_early = !KP && will_sweep && opt.force_order != 2 && rows > 0 && !getenv("CFS_HIP_NO_EARLY_NATURAL");
+  bool nat_done = false;
+  int nat_place_rc = 0, nat_rc = 0; // place()'s result; the cut's
+  std::string nat_why, nat_err;
+  DevBuf flagsN, ctrN;
+  Scratch tmpN;
+  unsigned long long h_ctrN[C_COUNT] = {0};
   // the upload of the caller's CSR (PCIe, all host threads copy into the page-locked pieces)
   // runs beside the clustering sweep of the host, which only reads the caller's arrays
   int up_rc = 0, cur_dev = 0;
@@ -1434,7 +1472,19 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   auto do_upload = [&]() {
     (void)hipSetDevice(cur_dev);
     up_rc = upload_input<V>(n, rowptr, colind, values, in);
-    if (up_rc) up_err = cfs_rt::last_error(); // (the message is thread-local)
+    if (up_rc) {
+      up_err = cfs_rt::last_error(); // (the message is thread-local)
+      return;
+    }
+    if (!nat_early) return;
+    int r = flagsN.alloc(F_COUNT * sizeof(int));
+    if (!r) r = ctrN.alloc(C_COUNT * 8);
+    if (!r && hipMemset(flagsN.p, 0, F_COUNT * sizeof(int)) != hipSuccess) r = CFS_HIP_ERR_DEVICE;
+    if (!r) r = place<V>(in, rb, re, mirror, nullptr, SN, tmpN, flagsN, h_ctrN, ctrN, nat_why);
+    nat_place_rc = r;
+    if (!r) nat_rc = cut_with(SN, FN, true, tmpN, flagsN, ctrN, nat_why);
+    if (nat_place_rc < 0 || nat_rc < 0) nat_err = cfs_rt::last_error();
+    nat_done = true;
   };
   std::thread uploader;
   bool threaded = false;
@@ -1504,28 +1554,6 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
   pt.lap("device: upload CSR || cluster_rows (host)");
   bool use_clustered = have_clusters;
   const bool reused = have_clusters && !same_clusters && cache && cache->valid && cache->nchunks == 2 * nc;
-  auto natural_chunks = [&](Sched &X) { // cfs_plan::Builder::cut_chunks
-    X.chunk.assign((size_t)nc + 1, re);
-    X.chunk[0] = rb;
-    const std::vector<double> share = L.shares(opt);
-    std::vector<double> cum((size_t)nc + 1, 0.0);
-    for (int c = 0; c < nc; c++) cum[c + 1] = cum[c] + share[c];
-    for (int c = 1; c < nc; c++) {
-      const int64_t target = (int64_t)((double)X.cost[rows] * (cum[c] / cum[nc]));
-      int r = (int)(std::lower_bound(X.cost.begin(), X.cost.end(), target) - X.cost.begin());
-      if (r > rows) r = rows;
-      if (rb + r < X.chunk[c - 1]) r = X.chunk[c - 1] - rb;
-      X.chunk[c] = rb + r;
-    }
-    X.chunk[nc] = re;
-  };
-  FarState FC, FN; // Format::hyb: the far entries of either order
-  auto cut = [&](Sched &X, FarState &F, bool natural) -> int {
-    row_costs<V>(X, nullptr, nullptr); // (a kept placement may hold the costs of an earlier HYB build)
-    if (natural) natural_chunks(X);
-    if (!opt.hyb) return cut_tiles<V>(X, L, opt, flags, why);
-    return hyb_cut<V>(X, F, L, opt, natural, natural_chunks, tmp, flags, ctr, why);
-  };
   if (have_clusters) {
     if (!K) {
       rc = place<V>(in, rb, re, mirror, &perm, SC, tmp, flags, h_ctr, ctr, why);
@@ -1539,9 +1567,19 @@ int build(int n, const int *rowptr, const int *colind, const V *values, int nran
     if (!c_ok) HIPCHK(hipMemset(flags.p, 0, F_COUNT * sizeof(int))); // natural order may still do
     pt.lap("device: clustered order placed + cut");
     if (opt.force_order != 2 && !reused) {
-      rc = place<V>(in, rb, re, mirror, nullptr, SN, tmp, flags, h_ctr, ctr, why);
-      if (rc) return rc;
-      if ((rc = cut(SN, FN, true)) < 0) return rc;
+      if (nat_done) { // placed and cut beside the clustering sweep
+        if (nat_place_rc < 0 || nat_rc < 0) return set_err(nat_place_rc < 0 ? nat_place_rc : nat_rc, nat_err);
+        if (nat_place_rc) { // place() itself handed over (unsorted rows, duplicates ...)
+          why = nat_why;
+          return nat_place_rc;
+        }
+        rc = nat_rc;
+        if (rc) why = nat_why;
+      } else {
+        rc = place<V>(in, rb, re, mirror, nullptr, SN, tmp, flags, h_ctr, ctr, why);
+        if (rc) return rc;
+        if ((rc = cut(SN, FN, true)) < 0) return rc;
+      }
       const bool n_ok = rc == 0;
       if (!n_ok && !c_ok) return kUseHost;
       if (!n_ok) HIPCHK(hipMemset(flags.p, 0, F_COUNT * sizeof(int)));
