@@ -35,8 +35,32 @@ using cfs_rt::set_err;
 
 static int ensure_init() { return cfs_rt::ensure_home(); }
 
+// copy with non-temporal stores (dst 16-byte aligned): a staging block is written once and read by the
+// DMA engine, never by this CPU -- ordinary stores would first read every destination line into the cache
+// (read-for-ownership: three memory transfers per byte instead of two; glibc only switches to streaming
+// stores for copies far larger than one thread's 1 MiB share of a piece)
+static void stream_copy(char *dst, const char *src, size_t n) {
+  typedef long long v2 __attribute__((vector_size(16), aligned(16)));
+  typedef long long v2u __attribute__((vector_size(16), aligned(1)));
+  if (((uintptr_t)dst & 15) != 0) {
+    memcpy(dst, src, n);
+    return;
+  }
+  size_t i = 0;
+  for (; i + 64 <= n; i += 64) {
+    const v2u a = *reinterpret_cast<const v2u *>(src + i), b = *reinterpret_cast<const v2u *>(src + i + 16),
+              c = *reinterpret_cast<const v2u *>(src + i + 32), d = *reinterpret_cast<const v2u *>(src + i + 48);
+    __builtin_nontemporal_store((v2)a, reinterpret_cast<v2 *>(dst + i));
+    __builtin_nontemporal_store((v2)b, reinterpret_cast<v2 *>(dst + i + 16));
+    __builtin_nontemporal_store((v2)c, reinterpret_cast<v2 *>(dst + i + 32));
+    __builtin_nontemporal_store((v2)d, reinterpret_cast<v2 *>(dst + i + 48));
+  }
+  if (i < n) memcpy(dst + i, src + i, n - i);
+  __builtin_ia32_sfence();
+}
 void cfs_rt::parallel_copy(void *dst, const void *src, size_t bytes) {
   const int T = cfs_plan::host_threads();
+  static const bool stream = !(getenv("CFS_HIP_STREAM_COPY") && atoi(getenv("CFS_HIP_STREAM_COPY")) == 0);
   if (bytes < ((size_t)1 << 20) || T < 2) {
     memcpy(dst, src, bytes);
     return;
@@ -45,7 +69,10 @@ void cfs_rt::parallel_copy(void *dst, const void *src, size_t bytes) {
 #pragma omp parallel for schedule(static) num_threads(T)
   for (int t = 0; t < T; t++) {
     const size_t b = (size_t)t * chunk;
-    if (b < bytes) memcpy((char *)dst + b, (const char *)src + b, std::min(chunk, bytes - b));
+    if (b >= bytes) continue;
+    const size_t len = std::min(chunk, bytes - b);
+    if (stream) stream_copy((char *)dst + b, (const char *)src + b, len);
+    else memcpy((char *)dst + b, (const char *)src + b, len);
   }
 }
 
