@@ -2293,6 +2293,7 @@ int cfs_hip_sym_spmv_async(cfs_hip_sym_t h, void *y, const void *x, void *stream
 int cfs_hip_sym_cg(cfs_hip_sym_t h, void *u_dev, const void *b_dev, double tol, int maxiter, int check_every,
                    int *iterations, double *relres, void *stream) {
   if (!h || !u_dev || !b_dev) return set_err(CFS_HIP_ERR_ARG, "null argument");
+  if (u_dev == b_dev) return set_err(CFS_HIP_ERR_ARG, "cg: u and b must be different vectors");
   if (iterations) *iterations = 0;
   if (relres) *relres = 0.0;
   if (!h->send_rows().empty())
